@@ -1,0 +1,136 @@
+"""Implementation of ``bench.py`` (kept in the package so tests can exercise it on CPU)."""
+from __future__ import annotations
+
+import os
+import time
+from typing import Optional
+
+import torch
+
+BASELINE_SINGLE = 55000.0 / 1.3
+BASELINE_MULTI = 3 * 55000.0 / 6.03
+BATCH = 100
+STEPS_PER_EPOCH = 550
+LR = 0.001
+
+
+def _dist_env():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def _sync(device, distributed: bool):
+    import torch.distributed as dist
+
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def run_benchmark(args) -> Optional[dict]:
+    import torch.distributed as dist
+
+    from .data import DeviceDataset, read_data_sets
+    from .parallel.replicas import build_replica_trainer
+
+    rank, local_rank, world = _dist_env()
+    n = int(args.gpus)
+    distributed = world > 1
+    if distributed and world != n:
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+    if n > 1 and not distributed:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    use_cpu = bool(args.cpu) or not torch.cuda.is_available()
+    if use_cpu:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group(backend="gloo" if use_cpu else "nccl",
+                                device_id=None if use_cpu else device)
+    mode = args.mode or ("single" if n == 1 else "sync")
+
+    sizes = (55000, 5000, 10000) if not use_cpu else (5500, 100, 1000)
+    mnist = read_data_sets("MNIST_data", one_hot=True, seed=0, sizes=sizes)
+    # Every worker trains on its own independently shuffled copy (tfdist_between.py:92).
+    ds = DeviceDataset(mnist.train.images, mnist.train.labels, device, BATCH, seed=1000 + rank)
+    trainer = build_replica_trainer(mode=mode, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
+                                    rank=rank, world=world, chunk=int(args.chunk),
+                                    use_graph=not args.no_graph)
+    steps, warmup = int(args.steps), int(args.warmup)
+
+    trainer.prepare(steps_hint=(warmup, steps))
+    trainer.run_steps(warmup)
+    _sync(device, distributed)
+    t0 = time.perf_counter()
+    trainer.run_steps(steps)
+    _sync(device, distributed)
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    test_x = torch.as_tensor(mnist.test.images).to(device)
+    test_y = torch.as_tensor(mnist.test.labels).to(device)
+    loss, acc = trainer.evaluate(test_x, test_y)
+    last_cost = trainer.last_loss()
+    global_step = trainer.global_step_value()
+
+    # Like-for-like epoch time: 550 steps + per-100-step host fetch of the cost +
+    # full test-set evaluation, as the reference's "Total Time" does (tfdist_between.py:86-111).
+    epoch_s = None
+    if steps >= STEPS_PER_EPOCH:
+        _sync(device, distributed)
+        te = time.perf_counter()
+        done = 0
+        while done < STEPS_PER_EPOCH:
+            k = min(100, STEPS_PER_EPOCH - done)
+            trainer.run_steps(k)
+            trainer.last_loss()
+            done += k
+        trainer.evaluate(test_x, test_y)
+        _sync(device, distributed)
+        epoch_s = time.perf_counter() - te
+
+    result = None
+    if rank == 0:
+        value = n * BATCH * steps / elapsed
+        base = BASELINE_SINGLE if n == 1 else BASELINE_MULTI
+        result = {
+            "metric": "samples/sec (784-100-10 MLP, batch 100/worker, SGD)",
+            "value": round(value, 1),
+            "unit": "samples/s",
+            "n_gpus": n,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(1000.0 * elapsed / steps, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(value / base, 2),
+            "dtype": "fp32",
+            "data": f"synthetic MNIST-shaped ({mnist.source}), random-init N(0,1) weights",
+            "config": {
+                "model": "tfsingle/tfdist_between 2-layer FC MLP 784-100-10 sigmoid+softmax",
+                "global_batch": n * BATCH,
+                "seq_len": None,
+                "parallelism": trainer.describe(),
+                "optimizer": "SGD lr=0.001",
+                "device": "cpu" if use_cpu else torch.cuda.get_device_name(device),
+            },
+            "sec_per_epoch": None if epoch_s is None else round(epoch_s, 5),
+            "sec_per_epoch_baseline": 1.3 if n == 1 else 5.35,
+            "test_accuracy_after_run": round(acc, 4),
+            "test_loss_after_run": round(loss, 4),
+            "last_cost": round(last_cost, 4),
+            "global_step": global_step,
+        }
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result

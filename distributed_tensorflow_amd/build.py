@@ -1,0 +1,112 @@
+"""In-tree build of the native libraries.
+
+Two shared objects are produced under ``distributed_tensorflow_amd/_lib``:
+
+* ``libdtf_hip.so`` — the gfx950 HIP kernels (``csrc/*.hip``), compiled with
+  ``hipcc --offload-arch=gfx950``.  hipcc cross-compiles, so this works on a
+  machine without a GPU.
+* ``libdtf_rt.so`` — the host-side C++ runtime (``runtime/*.cpp``): control
+  store / rendezvous server, TFRecord event writer, tensor-bundle checkpoint
+  writer.  Plain g++, no GPU dependency, usable in CPU-only tests.
+
+The libraries are loaded with ctypes (``ops/hip_backend.py``,
+``runtime/native.py``); nothing is installed outside the repository.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+RTSRC = PKG / "runtime"
+LIB = PKG / "_lib"
+
+HIP_LIB = LIB / "libdtf_hip.so"
+RT_LIB = LIB / "libdtf_rt.so"
+
+HIP_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-fno-gpu-rdc",
+    "-Wall",
+    "-Wno-unused-function",
+]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
+
+
+def _digest(paths, extra: str) -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _up_to_date(lib: Path, stamp: str) -> bool:
+    s = lib.with_suffix(".stamp")
+    return lib.exists() and s.exists() and s.read_text() == stamp
+
+
+def _run(cmd) -> None:
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        raise RuntimeError("build failed: " + " ".join(map(str, cmd)))
+    if proc.stdout.strip() and os.environ.get("DTF_BUILD_VERBOSE"):
+        print(proc.stdout)
+
+
+def build_hip(force: bool = False) -> Path:
+    LIB.mkdir(exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    hdrs = sorted(CSRC.glob("*.h"))
+    stamp = _digest(srcs + hdrs, " ".join(HIP_FLAGS))
+    if not force and _up_to_date(HIP_LIB, stamp):
+        return HIP_LIB
+    tmp = HIP_LIB.with_suffix(".so.tmp")
+    _run([_hipcc(), *HIP_FLAGS, f"-I{CSRC}", *map(str, srcs), "-o", str(tmp)])
+    os.replace(tmp, HIP_LIB)
+    HIP_LIB.with_suffix(".stamp").write_text(stamp)
+    return HIP_LIB
+
+
+def build_runtime(force: bool = False) -> Path:
+    LIB.mkdir(exist_ok=True)
+    srcs = sorted(RTSRC.glob("*.cpp"))
+    hdrs = sorted(RTSRC.glob("*.h"))
+    if not srcs:
+        raise RuntimeError("no runtime sources under %s" % RTSRC)
+    stamp = _digest(srcs + hdrs, " ".join(CXX_FLAGS))
+    if not force and _up_to_date(RT_LIB, stamp):
+        return RT_LIB
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    tmp = RT_LIB.with_suffix(".so.tmp")
+    _run([cxx, *CXX_FLAGS, f"-I{RTSRC}", *map(str, srcs), "-o", str(tmp)])
+    os.replace(tmp, RT_LIB)
+    RT_LIB.with_suffix(".stamp").write_text(stamp)
+    return RT_LIB
+
+
+def build_all(force: bool = False):
+    return build_hip(force), build_runtime(force)
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    for lib in build_all(force):
+        print("built", lib)

@@ -1,0 +1,85 @@
+// C ABI of libdtf_hip.so — the hand-written gfx950 kernels behind the MLP hot
+// path, the sharded SGD apply, gradient accumulation and the Philox initialiser.
+// Mirrored field-for-field by ctypes structures in ops/hip_backend.py.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// One training/eval problem instance: a 2-layer MLP
+//   a2 = act(x W1 + b1); y = softmax(a2 W2 + b2); loss = mean(-sum(y_ log y))
+// (the model of reference tfdist_between.py:55-62).  All pointers are device
+// pointers; parameter and gradient pointers normally alias ranges of the flat
+// per-shard slabs.
+typedef struct DtfMlpDesc {
+  int32_t in_dim;             // K (784)
+  int32_t hidden;             // H (100)
+  int32_t classes;            // C (10), at most 16
+  int32_t batch;              // B rows per step
+  int32_t act;                // DTF_ACT_*
+  int32_t ksplit;             // split-K factor of the first GEMM, 0 = auto
+  int32_t batches_per_epoch;  // cursor modulus, 0 = no wrap
+  int32_t hist_cap;           // length of loss_hist / acc_hist rings
+  const float* x;             // [batches_per_epoch*B, K] resident samples
+  const float* y;             // [batches_per_epoch*B, C] resident one-hot/soft labels
+  float* W1;                  // [K, H]
+  float* b1;                  // [H]
+  float* W2;                  // [H, C]
+  float* b2;                  // [C]
+  float* gW1;                 // gradient outputs (may be null in fused mode)
+  float* gb1;
+  float* gW2;
+  float* gb2;
+  float* z2;                  // [B, H] workspace, must start zeroed
+  float* dz2;                 // [B, H] workspace
+  int32_t* cursor;            // device int: batches consumed so far (may be null)
+  const float* lr;            // device float: learning rate
+  float* loss_hist;           // ring of per-step mean loss (may be null)
+  float* acc_hist;            // ring of per-step batch accuracy (may be null)
+  float* global_step;         // device float scalar bumped by fused steps (may be null)
+} DtfMlpDesc;
+
+// `bias` = position of this step inside a captured chunk (see dtf_common.h).
+// fwd + loss + bwd + in-place SGD in three launches.
+int dtf_mlp_step_fused(const DtfMlpDesc* d, int bias, void* stream);
+// fwd + loss + bwd writing gradients (scaled by grad_scale) to g*; no update.
+int dtf_mlp_step_grad(const DtfMlpDesc* d, int bias, float grad_scale, void* stream);
+// cursor += n  (one thread).
+int dtf_advance_cursor(int32_t* cursor, int n, void* stream);
+
+// Forward-only evaluation of M rows: accumulates sum of per-row losses into
+// loss_sum[0] and the number of correct argmax predictions into correct[0]
+// (both must be zeroed by the caller).  a2_ws is an [M, H] workspace.
+int dtf_mlp_eval(const float* x, const float* y, int M, int K, int H, int C, int act,
+                 const float* W1, const float* b1, const float* W2, const float* b2,
+                 float* a2_ws, float* loss_sum, int32_t* correct, void* stream);
+
+// Individual kernels (unit-tested against fp32 PyTorch oracles).
+// out[M,H] = act(x[M,K] W[K,H] + b[H])
+int dtf_linear_bias_act(const float* x, const float* W, const float* b, float* out,
+                        int M, int K, int H, int act, int ksplit, void* stream);
+// dW[K,H] = x[M,K]^T dz[M,H] * scale   (mode 0 store, 1: W -= lr*dW, 2: atomic add)
+int dtf_dw_gemm(const float* x, const float* dz, float* out, int M, int K, int H,
+                int mode, float scale, const float* lr, void* stream);
+
+// p[i] -= lr * scale * g[i]; optionally zero g afterwards; optionally
+// global_step += 1 (single thread).
+int dtf_sgd_apply(float* p, float* g, int64_t n, const float* lr, float scale,
+                  int zero_grad, float* global_step, void* stream);
+// acc[i] += g[i]
+int dtf_accumulate(float* acc, const float* g, int64_t n, void* stream);
+// Philox4x32-10 + Box-Muller normal fill: out[i] = mean + std * N(0,1), a pure
+// function of (seed, offset + i).
+int dtf_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float mean,
+                      float stddev, void* stream);
+// dst[i, :] = src[idx[i], :]   (epoch shuffle of the resident dataset)
+int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int cols,
+                    void* stream);
+
+const char* dtf_hip_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,34 @@
+// Launcher prototypes shared between the translation units of libdtf_hip.so.
+#pragma once
+#include "dtf_common.h"
+
+#define DTF_HEAD_EVAL 0
+#define DTF_HEAD_GRAD 1
+#define DTF_HEAD_FUSED 2
+
+struct DtfHeadLaunch {
+  float* zin;
+  int pre_act, zero_zin;
+  const float *b1, *W2, *b2, *ybase;
+  const int* cursor;
+  int bias, bpe;
+  float* dz2;
+  float *oW2, *ob2, *ob1;
+  float grad_scale;
+  const float* lr;
+  float* loss_sum;
+  int* correct;
+  float *loss_hist, *acc_hist;
+  int hist_cap;
+  float* global_step;
+  int M, H, C, act, mode;
+};
+
+int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream);
+int dtf_head_grid(int M, int H);
+int dtf_launch_fwd_gemm(const float* xbase, const int* cursor, int bias, int bpe, const float* W,
+                        const float* b, float* out, int M, int K, int H, int act, int ksplit,
+                        hipStream_t stream);
+int dtf_launch_dw_gemm(const float* xbase, const int* cursor, int bias, int bpe, const float* dZ,
+                       float* out, int M, int K, int H, int mode, float scale, const float* lr,
+                       hipStream_t stream);

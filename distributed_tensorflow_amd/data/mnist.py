@@ -1,0 +1,216 @@
+"""MNIST-shaped input pipeline.
+
+Mirrors the surface of the TF tutorial loader the reference uses
+(``input_data.read_data_sets("MNIST_data", one_hot=True)``,
+``mnist.train.num_examples``, ``mnist.train.next_batch(100)``,
+``mnist.test.images/.labels`` — reference tfdist_between.py:24-25, 88, 92, 109):
+55,000 train / 5,000 validation / 10,000 test rows of 784 float32 pixels in
+[0, 1] with one-hot float32 labels.
+
+There is no network here, so unless real idx files are present under the data
+directory the set is *synthetic*: ten fixed sparse class prototypes (about 20 %
+"ink" like a digit image) blended with per-sample stroke dropout, intensity
+jitter and background noise.  It is deterministic for a given seed, learnable
+by the 784-100-10 MLP, and not linearly trivial.
+
+``DeviceDataset`` keeps a split resident on the GPU and reshuffles it per epoch
+with a gather kernel, which removes the per-step host->device feed of the
+reference (313,600 B + 4,000 B per step).
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import struct
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+IMAGE_PIXELS = 784
+NUM_CLASSES = 10
+TRAIN_SIZE, VALIDATION_SIZE, TEST_SIZE = 55000, 5000, 10000
+
+
+def _one_hot(labels: np.ndarray, num_classes: int = NUM_CLASSES) -> np.ndarray:
+    out = np.zeros((labels.shape[0], num_classes), dtype=np.float32)
+    out[np.arange(labels.shape[0]), labels] = 1.0
+    return out
+
+
+def synthetic_mnist(n: int, seed: int, proto_seed: int = 1234) -> Tuple[np.ndarray, np.ndarray]:
+    """n rows of MNIST-shaped data: (images [n,784] f32 in [0,1], integer labels [n])."""
+    prng = np.random.RandomState(proto_seed)
+    # Prototypes: smooth blobs on a 28x28 grid, thresholded to ~20% ink.
+    protos = np.zeros((NUM_CLASSES, 28, 28), dtype=np.float32)
+    yy, xx = np.mgrid[0:28, 0:28].astype(np.float32)
+    for c in range(NUM_CLASSES):
+        img = np.zeros((28, 28), dtype=np.float32)
+        for _ in range(6):
+            cx, cy = prng.uniform(5, 23, size=2)
+            sx, sy = prng.uniform(1.5, 4.5, size=2)
+            img += np.exp(-(((xx - cx) / sx) ** 2 + ((yy - cy) / sy) ** 2))
+        thr = np.quantile(img, 0.80)
+        protos[c] = np.clip((img - thr) / (img.max() - thr + 1e-6), 0.0, 1.0)
+    protos = protos.reshape(NUM_CLASSES, IMAGE_PIXELS)
+
+    rng = np.random.RandomState(seed)
+    labels = rng.randint(0, NUM_CLASSES, size=n).astype(np.int64)
+    images = np.empty((n, IMAGE_PIXELS), dtype=np.float32)
+    chunk = 8192
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        lab = labels[s:e]
+        base = protos[lab]
+        # a second, weaker class bleeds in so that classes overlap
+        other = protos[(lab + rng.randint(1, NUM_CLASSES, size=e - s)) % NUM_CLASSES]
+        mix = rng.uniform(0.0, 0.45, size=(e - s, 1)).astype(np.float32)
+        gain = rng.uniform(0.55, 1.0, size=(e - s, 1)).astype(np.float32)
+        keep = (rng.uniform(size=(e - s, IMAGE_PIXELS)) > 0.25).astype(np.float32)
+        noise = rng.normal(0.0, 0.12, size=(e - s, IMAGE_PIXELS)).astype(np.float32)
+        img = gain * (base * keep + mix * other) + noise * (rng.uniform(size=(e - s, IMAGE_PIXELS)) < 0.3)
+        images[s:e] = np.clip(img, 0.0, 1.0)
+    return images, labels
+
+
+def _read_idx(path: str) -> np.ndarray:
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        magic = struct.unpack(">I", f.read(4))[0]
+        ndim = magic & 0xFF
+        dims = struct.unpack(">" + "I" * ndim, f.read(4 * ndim))
+        return np.frombuffer(f.read(), dtype=np.uint8).reshape(dims)
+
+
+def _find_idx(data_dir: str, stem: str) -> Optional[str]:
+    for suffix in (".gz", ""):
+        p = os.path.join(data_dir, stem + suffix)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+class DataSet:
+    """One split with TF-tutorial ``next_batch`` semantics (reshuffle at each epoch boundary)."""
+
+    def __init__(self, images: np.ndarray, labels: np.ndarray, seed: Optional[int] = None):
+        assert images.shape[0] == labels.shape[0]
+        self._images = images
+        self._labels = labels
+        self._num_examples = images.shape[0]
+        self._epochs_completed = 0
+        self._index_in_epoch = 0
+        self._rng = np.random.RandomState(seed)
+        self._shuffled_once = False
+
+    @property
+    def images(self) -> np.ndarray:
+        return self._images
+
+    @property
+    def labels(self) -> np.ndarray:
+        return self._labels
+
+    @property
+    def num_examples(self) -> int:
+        return self._num_examples
+
+    @property
+    def epochs_completed(self) -> int:
+        return self._epochs_completed
+
+    def _shuffle(self):
+        perm = self._rng.permutation(self._num_examples)
+        self._images = self._images[perm]
+        self._labels = self._labels[perm]
+
+    def next_batch(self, batch_size: int, shuffle: bool = True):
+        start = self._index_in_epoch
+        if start == 0 and self._epochs_completed == 0 and shuffle and not self._shuffled_once:
+            self._shuffle()
+            self._shuffled_once = True
+        if start + batch_size > self._num_examples:
+            self._epochs_completed += 1
+            rest = self._num_examples - start
+            img_rest, lab_rest = self._images[start:], self._labels[start:]
+            if shuffle:
+                self._shuffle()
+            self._index_in_epoch = batch_size - rest
+            end = self._index_in_epoch
+            return (np.concatenate((img_rest, self._images[:end]), axis=0),
+                    np.concatenate((lab_rest, self._labels[:end]), axis=0))
+        self._index_in_epoch += batch_size
+        end = self._index_in_epoch
+        return self._images[start:end], self._labels[start:end]
+
+
+class Datasets:
+    def __init__(self, train: DataSet, validation: DataSet, test: DataSet, source: str):
+        self.train, self.validation, self.test, self.source = train, validation, test, source
+
+
+_CACHE = {}
+
+
+def read_data_sets(train_dir: str = "MNIST_data", one_hot: bool = True, seed: int = 0,
+                   shuffle_seed: Optional[int] = None, sizes=(TRAIN_SIZE, VALIDATION_SIZE, TEST_SIZE)) -> Datasets:
+    """Real idx files under ``train_dir`` if present, else the synthetic set (never downloads)."""
+    n_train, n_val, n_test = sizes
+    paths = [_find_idx(train_dir, s) for s in ("train-images-idx3-ubyte", "train-labels-idx1-ubyte",
+                                                "t10k-images-idx3-ubyte", "t10k-labels-idx1-ubyte")]
+    if all(paths) and sizes == (TRAIN_SIZE, VALIDATION_SIZE, TEST_SIZE):
+        tr_i = _read_idx(paths[0]).reshape(-1, IMAGE_PIXELS).astype(np.float32) / 255.0
+        tr_l = _read_idx(paths[1]).astype(np.int64)
+        te_i = _read_idx(paths[2]).reshape(-1, IMAGE_PIXELS).astype(np.float32) / 255.0
+        te_l = _read_idx(paths[3]).astype(np.int64)
+        val_i, val_l = tr_i[:VALIDATION_SIZE], tr_l[:VALIDATION_SIZE]
+        tr_i, tr_l = tr_i[VALIDATION_SIZE:], tr_l[VALIDATION_SIZE:]
+        source = "mnist-idx"
+    else:
+        key = (seed, sizes)
+        if key not in _CACHE:
+            imgs, labs = synthetic_mnist(n_train + n_val + n_test, seed=seed + 17)
+            _CACHE[key] = (imgs, labs)
+        imgs, labs = _CACHE[key]
+        tr_i, tr_l = imgs[:n_train], labs[:n_train]
+        val_i, val_l = imgs[n_train:n_train + n_val], labs[n_train:n_train + n_val]
+        te_i, te_l = imgs[n_train + n_val:], labs[n_train + n_val:]
+        source = "synthetic"
+    conv = _one_hot if one_hot else (lambda a: a)
+    return Datasets(DataSet(tr_i, conv(tr_l), shuffle_seed), DataSet(val_i, conv(val_l), shuffle_seed),
+                    DataSet(te_i, conv(te_l), shuffle_seed), source)
+
+
+class DeviceDataset:
+    """A split held on the training device, reshuffled per epoch without touching the host.
+
+    ``x_epoch`` / ``y_epoch`` are the tensors an :class:`MLPEngine` binds to; the
+    storage never moves, so hipGraphs captured against it stay valid across
+    epochs.  Every worker shuffles independently (no sharding between workers —
+    reference tfdist_between.py:92 draws from a private copy of the set).
+    """
+
+    def __init__(self, images, labels, device, batch_size: int, seed: int = 0):
+        self.device = torch.device(device)
+        self.x = torch.as_tensor(images, dtype=torch.float32).contiguous().to(self.device)
+        self.y = torch.as_tensor(labels, dtype=torch.float32).contiguous().to(self.device)
+        self.num_examples = self.x.shape[0]
+        self.batch_size = int(batch_size)
+        self.batches_per_epoch = self.num_examples // self.batch_size
+        self.x_epoch = torch.empty_like(self.x)
+        self.y_epoch = torch.empty_like(self.y)
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(seed)
+        self.epoch = -1
+        self.shuffle_epoch()
+
+    def shuffle_epoch(self):
+        perm = torch.randperm(self.num_examples, generator=self._gen).to(self.device)
+        if self.device.type == "cuda":
+            from ..ops import hip_backend as hb
+            hb.gather_rows(self.x, perm, self.x_epoch)
+            hb.gather_rows(self.y, perm, self.y_epoch)
+        else:
+            torch.index_select(self.x, 0, perm, out=self.x_epoch)
+            torch.index_select(self.y, 0, perm, out=self.y_epoch)
+        self.epoch += 1

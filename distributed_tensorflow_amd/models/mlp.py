@@ -1,0 +1,256 @@
+"""The reference workload as a device-resident engine.
+
+``MLPEngine`` binds the fused gfx950 kernels (csrc/mlp_gemm.hip, mlp_head.hip)
+to a set of parameter / gradient tensors — normally views into the flat
+per-shard slabs of :mod:`distributed_tensorflow_amd.variables` — and exposes the
+three step flavours every training mode is built from:
+
+* ``step_fused``  forward + loss + backward + in-place SGD (single process;
+  reference tfsingle.py:46-49, 78-80) in three kernel launches;
+* ``step_grad``   forward + loss + backward into the gradient slab (workers of
+  the PS modes; the push/apply happens in the transport);
+* ``evaluate``    forward-only accuracy/loss over a large batch (the per-epoch
+  test pass, reference tfdist_between.py:109).
+
+The training set stays resident in HBM (55,000 x 784 fp32 = 172 MB of 288 GB),
+so a step needs no host->device copy; mini-batches are addressed through a
+device-side cursor, which lets any number of steps be captured into a single
+hipGraph and replayed with one host call (``run_chunk``).
+
+On CPU tensors every method runs the PyTorch reference implementation with the
+same semantics, which is both the soft-placement fallback and the test oracle.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from ..ops import hip_backend as hb
+from ..ops import reference as ref
+
+
+class MLPEngine:
+    PARAM_NAMES = ("W1", "b1", "W2", "b2")
+
+    def __init__(
+        self,
+        params: Dict[str, torch.Tensor],
+        grads: Optional[Dict[str, torch.Tensor]] = None,
+        *,
+        batch: int,
+        lr: float,
+        act="sigmoid",
+        hist_cap: int = 8192,
+        global_step: Optional[torch.Tensor] = None,
+        ksplit: int = 0,
+    ):
+        self.p = {k: params[k] for k in self.PARAM_NAMES}
+        self.g = None if grads is None else {k: grads[k] for k in self.PARAM_NAMES}
+        W1, W2 = self.p["W1"], self.p["W2"]
+        self.device = W1.device
+        self.K, self.H = W1.shape
+        self.C = W2.shape[1]
+        if W2.shape[0] != self.H or self.p["b1"].numel() != self.H or self.p["b2"].numel() != self.C:
+            raise ValueError("inconsistent MLP parameter shapes")
+        self.B = int(batch)
+        self.act = ref.act_code(act)
+        self.on_gpu = self.device.type == "cuda"
+        if self.on_gpu:
+            hb.require()
+        dev = self.device
+        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.cursor = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.hist_cap = int(hist_cap)
+        self.loss_hist = torch.zeros((self.hist_cap,), dtype=torch.float32, device=dev)
+        self.acc_hist = torch.zeros((self.hist_cap,), dtype=torch.float32, device=dev)
+        self.z2 = torch.zeros((self.B, self.H), dtype=torch.float32, device=dev)
+        self.dz2 = torch.zeros((self.B, self.H), dtype=torch.float32, device=dev)
+        self.global_step = global_step
+        self.ksplit = int(ksplit)
+        self.x = None
+        self.y = None
+        self.batches_per_epoch = 0
+        self._host_cursor = 0  # CPU path only
+        self._desc = None
+        self._graphs = {}
+        self._eval_ws = None
+        self._eval_acc = None
+
+    # -- data ---------------------------------------------------------------
+    def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
+        """Attach resident sample/label matrices; batch b is rows [b*B, (b+1)*B)."""
+        if x.device != self.device or y.device != self.device:
+            raise ValueError("dataset must live on the engine's device")
+        if x.dtype != torch.float32 or y.dtype != torch.float32 or not x.is_contiguous() or not y.is_contiguous():
+            raise ValueError("dataset must be contiguous float32")
+        if x.shape[1] != self.K or y.shape[1] != self.C or x.shape[0] != y.shape[0]:
+            raise ValueError("dataset shape does not match the model")
+        nb = x.shape[0] // self.B
+        if batches_per_epoch is None:
+            batches_per_epoch = nb
+        if batches_per_epoch < 1 or batches_per_epoch > nb:
+            raise ValueError("not enough rows for the requested batches_per_epoch")
+        rebuilt = (self.x is None or self.x.data_ptr() != x.data_ptr() or self.y.data_ptr() != y.data_ptr()
+                   or self.batches_per_epoch != batches_per_epoch)
+        self.x, self.y, self.batches_per_epoch = x, y, int(batches_per_epoch)
+        if rebuilt:
+            self._desc = None
+            self._graphs.clear()
+
+    def set_cursor(self, value: int):
+        self._host_cursor = int(value)
+        self.cursor.fill_(int(value))
+
+    def set_lr(self, lr: float):
+        self.lr.fill_(float(lr))
+
+    # -- descriptor -----------------------------------------------------------
+    def _descriptor(self) -> "hb.DtfMlpDesc":
+        if self._desc is not None:
+            return self._desc
+        if self.x is None:
+            raise RuntimeError("bind_data() must be called before stepping")
+        d = hb.DtfMlpDesc()
+        d.in_dim, d.hidden, d.classes, d.batch = self.K, self.H, self.C, self.B
+        d.act, d.ksplit = self.act, self.ksplit
+        d.batches_per_epoch, d.hist_cap = self.batches_per_epoch, self.hist_cap
+        d.x, d.y = self.x.data_ptr(), self.y.data_ptr()
+        for k in self.PARAM_NAMES:
+            t = self.p[k]
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError(f"parameter {k} must be contiguous float32")
+            setattr(d, k, t.data_ptr())
+            if self.g is not None:
+                gt = self.g[k]
+                if not gt.is_contiguous() or gt.shape != t.shape:
+                    raise ValueError(f"gradient {k} must be contiguous and parameter-shaped")
+                setattr(d, "g" + k, gt.data_ptr())
+        d.z2, d.dz2 = self.z2.data_ptr(), self.dz2.data_ptr()
+        d.cursor, d.lr = self.cursor.data_ptr(), self.lr.data_ptr()
+        d.loss_hist, d.acc_hist = self.loss_hist.data_ptr(), self.acc_hist.data_ptr()
+        d.global_step = self.global_step.data_ptr() if self.global_step is not None else None
+        self._desc = d
+        return d
+
+    # -- CPU reference path -----------------------------------------------------
+    def _cpu_batch(self, bias: int):
+        b = (self._host_cursor + bias) % self.batches_per_epoch
+        sl = slice(b * self.B, (b + 1) * self.B)
+        return self.x[sl], self.y[sl]
+
+    def _cpu_step(self, bias: int, fused: bool, scale: float):
+        xb, yb = self._cpu_batch(bias)
+        out = ref.mlp_grads(xb, yb, self.p["W1"], self.p["b1"], self.p["W2"], self.p["b2"], self.act)
+        slot = (self._host_cursor + bias) % self.hist_cap
+        self.loss_hist[slot] = out["loss"]
+        self.acc_hist[slot] = out["acc"]
+        lr = float(self.lr.item())
+        for k in self.PARAM_NAMES:
+            if fused:
+                self.p[k].sub_(out["d" + k], alpha=lr)
+            else:
+                self.g[k].copy_(out["d" + k] * scale)
+        if fused and self.global_step is not None:
+            self.global_step.add_(1.0)
+
+    # -- steps ----------------------------------------------------------------
+    def step_fused(self, bias: int = 0):
+        """One SGD step on batch (cursor + bias); does not move the cursor."""
+        if self.on_gpu:
+            hb.mlp_step_fused(self._descriptor(), bias)
+        else:
+            self._cpu_step(bias, True, 1.0)
+
+    def step_grad(self, bias: int = 0, scale: float = 1.0):
+        """Gradients of batch (cursor + bias) into the gradient tensors; no update."""
+        if self.g is None:
+            raise RuntimeError("engine was built without gradient tensors")
+        if self.on_gpu:
+            hb.mlp_step_grad(self._descriptor(), bias, scale)
+        else:
+            self._cpu_step(bias, False, scale)
+
+    def advance(self, n: int = 1):
+        if self.on_gpu:
+            hb.advance_cursor(self.cursor, n)
+        else:
+            self.cursor.add_(n)
+        self._host_cursor += n
+
+    def run_chunk(self, n: int, use_graph: bool = True):
+        """``n`` fused steps on consecutive batches, then cursor += n.
+
+        On the GPU the 3n+1 launches are captured once per ``n`` into a hipGraph
+        and replayed; the host issues a single call per chunk.
+        """
+        if n <= 0:
+            return
+        if not self.on_gpu or not use_graph:
+            for i in range(n):
+                self.step_fused(i)
+            self.advance(n)
+            return
+        g = self._graphs.get(n)
+        if g is None:
+            g = self._capture(n)
+            self._graphs[n] = g
+        g.replay()
+        self._host_cursor += n
+
+    def _capture(self, n: int) -> "torch.cuda.CUDAGraph":
+        self._descriptor()
+        # Warm up on a side stream (module load, attribute set) without
+        # disturbing training state: snapshot and restore what a step mutates.
+        saved = {k: v.clone() for k, v in self.p.items()}
+        saved_gs = self.global_step.clone() if self.global_step is not None else None
+        saved_hist = (self.loss_hist.clone(), self.acc_hist.clone())
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.step_fused(0)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        for k, v in saved.items():
+            self.p[k].copy_(v)
+        if saved_gs is not None:
+            self.global_step.copy_(saved_gs)
+        self.loss_hist.copy_(saved_hist[0])
+        self.acc_hist.copy_(saved_hist[1])
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(n):
+                hb.mlp_step_fused(self._desc, i)
+            hb.advance_cursor(self.cursor, n)
+        return graph
+
+    # -- evaluation ---------------------------------------------------------------
+    def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
+        """Mean loss and accuracy of the current parameters on (x, y); syncs the host."""
+        if not self.on_gpu:
+            loss, acc = ref.mlp_loss_acc(x, y, self.p["W1"], self.p["b1"], self.p["W2"], self.p["b2"], self.act)
+            return float(loss), float(acc)
+        M = x.shape[0]
+        if self._eval_ws is None or self._eval_ws.numel() < M * self.H:
+            self._eval_ws = torch.empty((M * self.H,), dtype=torch.float32, device=self.device)
+            self._eval_acc = (torch.zeros((1,), dtype=torch.float32, device=self.device),
+                              torch.zeros((1,), dtype=torch.int32, device=self.device))
+        loss_sum, correct = self._eval_acc
+        loss_sum.zero_()
+        correct.zero_()
+        hb.mlp_eval(x, y, self.p["W1"], self.p["b1"], self.p["W2"], self.p["b2"], self.act, self._eval_ws,
+                    loss_sum, correct)
+        return float(loss_sum.item()) / M, float(correct.item()) / M
+
+    # -- history --------------------------------------------------------------------
+    def history(self, first_step: int, count: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Per-step (loss, batch accuracy) for steps [first_step, first_step+count) as CPU tensors."""
+        if count > self.hist_cap:
+            raise ValueError("history window larger than the ring")
+        idx = (torch.arange(first_step, first_step + count) % self.hist_cap).to(self.device)
+        return self.loss_hist[idx].cpu(), self.acc_hist[idx].cpu()
+
+    def last_loss(self) -> float:
+        slot = (self._host_cursor - 1) % self.hist_cap
+        return float(self.loss_hist[slot].item())

@@ -1,0 +1,247 @@
+"""ctypes binding of ``_lib/libdtf_hip.so`` (the gfx950 kernels in ``csrc/``).
+
+The library is built in-tree by :mod:`distributed_tensorflow_amd.build` and is
+loaded lazily.  On a machine with a GPU a missing library is a hard error —
+there is no silent PyTorch fallback for CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "_lib" / "libdtf_hip.so"
+_lib: Optional[C.CDLL] = None
+_load_error: Optional[str] = None
+
+ERR_NAMES = {1: "bad shape/alignment", 2: "null pointer", 3: "launch failed", 4: "unsupported configuration"}
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class DtfMlpDesc(C.Structure):
+    """Field-for-field mirror of ``struct DtfMlpDesc`` in csrc/dtf_api.h."""
+
+    _fields_ = [
+        ("in_dim", C.c_int32),
+        ("hidden", C.c_int32),
+        ("classes", C.c_int32),
+        ("batch", C.c_int32),
+        ("act", C.c_int32),
+        ("ksplit", C.c_int32),
+        ("batches_per_epoch", C.c_int32),
+        ("hist_cap", C.c_int32),
+        ("x", C.c_void_p),
+        ("y", C.c_void_p),
+        ("W1", C.c_void_p),
+        ("b1", C.c_void_p),
+        ("W2", C.c_void_p),
+        ("b2", C.c_void_p),
+        ("gW1", C.c_void_p),
+        ("gb1", C.c_void_p),
+        ("gW2", C.c_void_p),
+        ("gb2", C.c_void_p),
+        ("z2", C.c_void_p),
+        ("dz2", C.c_void_p),
+        ("cursor", C.c_void_p),
+        ("lr", C.c_void_p),
+        ("loss_hist", C.c_void_p),
+        ("acc_hist", C.c_void_p),
+        ("global_step", C.c_void_p),
+    ]
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    lib.dtf_mlp_step_fused.argtypes = [C.POINTER(DtfMlpDesc), i32, vp]
+    lib.dtf_mlp_step_grad.argtypes = [C.POINTER(DtfMlpDesc), i32, f32, vp]
+    lib.dtf_advance_cursor.argtypes = [vp, i32, vp]
+    lib.dtf_mlp_eval.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dtf_linear_bias_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.dtf_dw_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]
+    lib.dtf_sgd_apply.argtypes = [vp, vp, i64, vp, f32, i32, vp, vp]
+    lib.dtf_accumulate.argtypes = [vp, vp, i64, vp]
+    lib.dtf_philox_normal.argtypes = [vp, i64, u64, u64, f32, f32, vp]
+    lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.dtf_hip_build_info.restype = C.c_char_p
+    for name in ("dtf_mlp_step_fused", "dtf_mlp_step_grad", "dtf_advance_cursor", "dtf_mlp_eval",
+                 "dtf_linear_bias_act", "dtf_dw_gemm", "dtf_sgd_apply", "dtf_accumulate",
+                 "dtf_philox_normal", "dtf_gather_rows"):
+        getattr(lib, name).restype = C.c_int
+
+
+def load(required: bool = False) -> Optional[C.CDLL]:
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is None:
+        try:
+            if not _LIB_PATH.exists():
+                raise OSError(f"{_LIB_PATH} not built (run `python -m distributed_tensorflow_amd.build`)")
+            lib = C.CDLL(str(_LIB_PATH), mode=C.RTLD_GLOBAL)
+            _declare(lib)
+            _lib = lib
+            return _lib
+        except OSError as e:  # pragma: no cover - depends on the machine
+            _load_error = str(e)
+    if required:
+        raise HipKernelError(f"HIP kernel library unavailable: {_load_error}")
+    return None
+
+
+def available() -> bool:
+    """True when the kernels can actually run: library loadable AND a GPU present."""
+    return torch.cuda.is_available() and load() is not None
+
+
+def require() -> C.CDLL:
+    return load(required=True)
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipKernelError(f"{what}: {ERR_NAMES.get(rc, rc)}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise HipKernelError(f"{name} must be a contiguous float32 CUDA tensor, got {t.dtype} {t.device}")
+    return t
+
+
+# ---------------------------------------------------------------------------
+# thin op wrappers
+# ---------------------------------------------------------------------------
+
+def linear_bias_act(x, W, b, act: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = require()
+    _f32c(x, "x"), _f32c(W, "W"), _f32c(b, "b")
+    M, K = x.shape
+    K2, H = W.shape
+    if K2 != K or b.numel() != H:
+        raise HipKernelError(f"linear_bias_act shape mismatch x{tuple(x.shape)} W{tuple(W.shape)} b{tuple(b.shape)}")
+    if out is None:
+        out = torch.empty((M, H), device=x.device, dtype=torch.float32)
+    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), _ptr(b), _ptr(out), M, K, H, act, 1, _stream()),
+           "dtf_linear_bias_act")
+    return out
+
+
+def linear_splitk(x, W, ksplit: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Raw x@W through the split-K/atomic path (accumulates into ``out``, zeroed if not given)."""
+    lib = require()
+    _f32c(x, "x"), _f32c(W, "W")
+    M, K = x.shape
+    H = W.shape[1]
+    if W.shape[0] != K:
+        raise HipKernelError("linear_splitk shape mismatch")
+    if out is None:
+        out = torch.zeros((M, H), device=x.device, dtype=torch.float32)
+    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), None, _ptr(out), M, K, H, 0, int(ksplit), _stream()),
+           "dtf_linear_bias_act(splitk)")
+    return out
+
+
+def dw_gemm(x, dz, out: Optional[torch.Tensor] = None, mode: int = 0, scale: float = 1.0,
+            lr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = require()
+    _f32c(x, "x"), _f32c(dz, "dz")
+    M, K = x.shape
+    M2, H = dz.shape
+    if M2 != M:
+        raise HipKernelError("dw_gemm: batch mismatch")
+    if out is None:
+        out = torch.zeros((K, H), device=x.device, dtype=torch.float32)
+    if tuple(out.shape) != (K, H):
+        raise HipKernelError("dw_gemm: bad output shape")
+    _check(lib.dtf_dw_gemm(_ptr(x), _ptr(dz), _ptr(out), M, K, H, mode, float(scale), _ptr(lr), _stream()),
+           "dtf_dw_gemm")
+    return out
+
+
+def sgd_apply_(p, g, lr: torch.Tensor, scale: float = 1.0, zero_grad: bool = False,
+               global_step: Optional[torch.Tensor] = None):
+    lib = require()
+    _f32c(p, "p"), _f32c(g, "g"), _f32c(lr, "lr")
+    if p.numel() != g.numel():
+        raise HipKernelError("sgd_apply: size mismatch")
+    _check(lib.dtf_sgd_apply(_ptr(p), _ptr(g), p.numel(), _ptr(lr), float(scale), int(zero_grad),
+                             _ptr(global_step), _stream()), "dtf_sgd_apply")
+    return p
+
+
+def accumulate_(acc, g):
+    lib = require()
+    _f32c(acc, "acc"), _f32c(g, "g")
+    if acc.numel() != g.numel():
+        raise HipKernelError("accumulate: size mismatch")
+    _check(lib.dtf_accumulate(_ptr(acc), _ptr(g), acc.numel(), _stream()), "dtf_accumulate")
+    return acc
+
+
+def philox_normal_(out, seed: int, offset: int = 0, mean: float = 0.0, stddev: float = 1.0):
+    lib = require()
+    _f32c(out, "out")
+    _check(lib.dtf_philox_normal(_ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset), float(mean),
+                                 float(stddev), _stream()), "dtf_philox_normal")
+    return out
+
+
+def gather_rows(src, idx, out: Optional[torch.Tensor] = None):
+    lib = require()
+    _f32c(src, "src")
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise HipKernelError("gather_rows: idx must be contiguous int64 CUDA tensor")
+    rows, cols = idx.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty((rows, cols), device=src.device, dtype=torch.float32)
+    if out.shape[0] < rows or out.shape[1] != cols:
+        raise HipKernelError("gather_rows: bad output shape")
+    _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, _stream()), "dtf_gather_rows")
+    return out
+
+
+def mlp_eval(x, y, W1, b1, W2, b2, act: int, a2_ws, loss_sum, correct):
+    lib = require()
+    for n, t in (("x", x), ("y", y), ("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2), ("a2_ws", a2_ws),
+                 ("loss_sum", loss_sum)):
+        _f32c(t, n)
+    M, K = x.shape
+    H, Cc = W2.shape
+    if W1.shape != (K, H) or y.shape != (M, Cc) or a2_ws.numel() < M * H or correct.dtype != torch.int32:
+        raise HipKernelError("mlp_eval: shape mismatch")
+    _check(lib.dtf_mlp_eval(_ptr(x), _ptr(y), M, K, H, Cc, act, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                            _ptr(a2_ws), _ptr(loss_sum), _ptr(correct), _stream()), "dtf_mlp_eval")
+
+
+def mlp_step_fused(desc: DtfMlpDesc, bias: int = 0):
+    _check(require().dtf_mlp_step_fused(C.byref(desc), int(bias), _stream()), "dtf_mlp_step_fused")
+
+
+def mlp_step_grad(desc: DtfMlpDesc, bias: int = 0, grad_scale: float = 1.0):
+    _check(require().dtf_mlp_step_grad(C.byref(desc), int(bias), float(grad_scale), _stream()),
+           "dtf_mlp_step_grad")
+
+
+def advance_cursor(cursor: torch.Tensor, n: int):
+    _check(require().dtf_advance_cursor(_ptr(cursor), int(n), _stream()), "dtf_advance_cursor")
+
+
+def build_info() -> str:
+    lib = load()
+    return lib.dtf_hip_build_info().decode() if lib is not None else "unavailable"

@@ -1,0 +1,273 @@
+"""Device-resident replica trainers: the fast tier used by ``bench.py`` and the scripts.
+
+One process per GPU.  Every process is worker *r* AND the owner of PS shard *r*
+(GPU-resident: the shard is a range of a flat fp32 slab in that GPU's HBM).
+
+* ``SingleTrainer``   — no PS: fused forward/backward/SGD, steps captured in
+  hipGraphs (reference tfsingle.py).
+* ``SyncShardTrainer`` — SyncReplicasOptimizer semantics (reference
+  tfdist_between_sync.py:65-68) without its queues: gradients are
+  **reduce-scattered** to the shard owners (= every accumulator receives all N
+  gradients), each owner applies the mean with the SGD kernel on its shard and
+  bumps ``global_step`` once, and the new parameters are **all-gathered** back
+  (= the pull of the next step).  ``replicas_to_aggregate == total_num_replicas
+  == world``; the completion of the collective is the token.
+* ``TowerTrainer``    — in-graph-replication semantics (one logical client, N
+  towers): gradients are all-reduce-averaged over RCCL and every tower applies
+  the identical update to its replica of the variables.
+* ``AsyncAllToAllTrainer`` — asynchronous update *rule* (every worker's gradient
+  is applied separately, unaveraged, to the owning shard; ``global_step``
+  advances by N per round) executed in lock step with collectives.  The truly
+  unsynchronised variant lives in :mod:`parallel.ps_ipc`.
+
+Collectives go through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI
+on the GPUs, ``gloo`` in CPU tests).  The message is 318 KB, i.e. latency-bound:
+one fused slab per collective, never one call per variable.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from ..models.mlp import MLPEngine
+from ..ops import hip_backend as hb
+from ..ops import reference as ref
+from ..variables import ShardLayout, assign_shards, mlp_var_specs
+
+
+class _BaseTrainer:
+    name = "base"
+
+    def __init__(self, device, dataset, batch: int, lr: float, seed: int, rank: int = 0, world: int = 1,
+                 chunk: int = 50, use_graph: bool = True, layout_mode: str = "flat", act: str = "sigmoid",
+                 dims: Tuple[int, int, int] = (784, 100, 10), need_grads: bool = True):
+        self.device = torch.device(device)
+        self.ds = dataset
+        self.rank, self.world = rank, world
+        self.chunk = max(1, int(chunk))
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        specs = mlp_var_specs(*dims)
+        assign_shards(specs, world)
+        self.layout = ShardLayout(specs, world, mode=layout_mode)
+        self.params = self.layout.new_slab(self.device)
+        self.layout.initialize(self.params, seed)   # same seed everywhere -> identical replicas
+        self.grads = self.layout.new_slab(self.device) if need_grads else None
+        self.global_step = self.layout.view(self.params, "global_step").view(1)
+        self.engine = MLPEngine(
+            self.layout.mlp_views(self.params),
+            self.layout.mlp_views(self.grads) if need_grads else None,
+            batch=batch, lr=lr, act=act, global_step=None,
+        )
+        self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self.lr = self.engine.lr
+        self.steps_done = 0
+        self._graphs = {}
+
+    # -- to be provided ---------------------------------------------------------
+    def _one_step(self, bias: int):
+        raise NotImplementedError
+
+    def describe(self) -> str:
+        return self.name
+
+    # -- common driver -------------------------------------------------------------
+    def _schedule(self, cursor: int, n: int):
+        """Chunk sizes run_steps() will use for n steps starting at ``cursor``."""
+        bpe = self.engine.batches_per_epoch
+        out = []
+        while n > 0:
+            k = min(n, self.chunk, bpe - cursor % bpe)
+            out.append(k)
+            cursor += k
+            n -= k
+        return out
+
+    def prepare(self, steps_hint=()):
+        """Capture every chunk graph the hinted run_steps() calls will need, outside any timed region."""
+        if not self.use_graph:
+            return
+        cursor = self.engine._host_cursor
+        sizes = set()
+        for n in steps_hint:
+            sizes.update(self._schedule(cursor, n))
+            cursor += n
+        for n in sorted(sizes):
+            self._get_graph(n)
+
+    def _run_eager(self, n: int):
+        for i in range(n):
+            self._one_step(i)
+        self.engine.advance(n)
+
+    def _get_graph(self, n: int):
+        g = self._graphs.get(n)
+        if g is None:
+            g = self._capture(n)
+            self._graphs[n] = g
+        return g
+
+    def _snapshot(self):
+        return (self.params.clone(), None if self.grads is None else self.grads.clone(),
+                self.engine.loss_hist.clone(), self.engine.acc_hist.clone(), self.engine.cursor.clone())
+
+    def _restore(self, snap):
+        self.params.copy_(snap[0])
+        if self.grads is not None:
+            self.grads.copy_(snap[1])
+        self.engine.loss_hist.copy_(snap[2])
+        self.engine.acc_hist.copy_(snap[3])
+        self.engine.cursor.copy_(snap[4])
+
+    def _capture(self, n: int):
+        # Eager warm-up on a side stream (lazy module loads, communicator set-up),
+        # with the training state restored afterwards.
+        snap = self._snapshot()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._one_step(0)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._restore(snap)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for i in range(n):
+                self._one_step(i)
+            hb.advance_cursor(self.engine.cursor, n)
+        return graph
+
+    def run_steps(self, n: int):
+        """n worker steps; reshuffles the resident set at every epoch boundary."""
+        bpe = self.engine.batches_per_epoch
+        for k in self._schedule(self.engine._host_cursor, n):
+            cur = self.engine._host_cursor
+            if cur % bpe == 0 and cur > 0:
+                self.ds.shuffle_epoch()
+            if self.use_graph:
+                self._get_graph(k).replay()
+                self.engine._host_cursor += k
+            else:
+                self._run_eager(k)
+            self.steps_done += k
+
+    def evaluate(self, x, y):
+        return self.engine.evaluate(x, y)
+
+    def last_loss(self) -> float:
+        return self.engine.last_loss()
+
+    def global_step_value(self) -> int:
+        return int(round(float(self.global_step.item())))
+
+
+class SingleTrainer(_BaseTrainer):
+    name = "single"
+
+    def __init__(self, *a, **kw):
+        kw["need_grads"] = False
+        super().__init__(*a, **kw)
+        # fused path bumps global_step inside the head kernel
+        self.engine.global_step = self.global_step
+        self.engine._desc = None
+
+    def _one_step(self, bias: int):
+        self.engine.step_fused(bias)
+
+    def describe(self):
+        return "single (no PS): 3 fused kernels/step, hipGraph chunks of %d" % self.chunk if self.use_graph \
+            else "single (no PS): 3 fused kernels/step, eager"
+
+
+class _CollectiveTrainer(_BaseTrainer):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        import torch.distributed as dist
+
+        self.dist = dist
+        if self.world > 1 and not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised for world > 1")
+        self.my_params = self.layout.shard_view(self.params, self.rank)
+        self.my_grads = self.layout.shard_view(self.grads, self.rank)
+        a0, b0 = self.layout.shard_range[self.rank]
+        o, _ = self.layout.var_range["global_step"]
+        self.owns_step = a0 <= o < b0
+
+    def _apply(self, p, g, scale: float, bump: bool):
+        if self.device.type == "cuda":
+            hb.sgd_apply_(p, g, self.lr, scale=scale, zero_grad=False,
+                          global_step=self.global_step if bump else None)
+        else:
+            ref.sgd_apply_(p, g, float(self.lr.item()), scale)
+            if bump:
+                self.global_step.add_(1.0)
+
+
+class SyncShardTrainer(_CollectiveTrainer):
+    name = "sync"
+
+    def _one_step(self, bias: int):
+        d = self.dist
+        # gradients pre-scaled by 1/N so that the reduce-scatter SUM is the mean
+        self.engine.step_grad(bias, scale=1.0 / self.world)
+        if self.world > 1:
+            d.reduce_scatter_tensor(self.my_grads, self.grads, op=d.ReduceOp.SUM)
+        self._apply(self.my_params, self.my_grads, 1.0, bump=self.owns_step)
+        if self.world > 1:
+            d.all_gather_into_tensor(self.params, self.my_params)
+
+    def describe(self):
+        return (f"sync-replicas dp{self.world}: PS shard per GPU, reduce-scatter -> sharded SGD -> all-gather "
+                f"(replicas_to_aggregate={self.world})" + (", hipGraph" if self.use_graph else ", eager"))
+
+
+class TowerTrainer(_CollectiveTrainer):
+    name = "towers"
+
+    def _one_step(self, bias: int):
+        d = self.dist
+        self.engine.step_grad(bias, scale=1.0 / self.world)
+        if self.world > 1:
+            d.all_reduce(self.grads, op=d.ReduceOp.SUM)
+        self._apply(self.params, self.grads, 1.0, bump=True)
+
+    def describe(self):
+        return f"in-graph towers dp{self.world}: all-reduce gradient averaging, replicated apply" + \
+            (", hipGraph" if self.use_graph else ", eager")
+
+
+class AsyncAllToAllTrainer(_CollectiveTrainer):
+    """Async update rule in lock step: shard owners apply each worker's gradient separately."""
+
+    name = "async"
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        n = self.layout.shard_numel(self.rank)
+        self.inbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
+
+    def _one_step(self, bias: int):
+        d = self.dist
+        self.engine.step_grad(bias, scale=1.0)
+        if self.world > 1:
+            d.all_to_all_single(self.inbox.view(-1), self.grads)
+            for w in range(self.world):   # N separate unaveraged applies, N global_step bumps
+                self._apply(self.my_params, self.inbox[w], 1.0, bump=self.owns_step)
+            d.all_gather_into_tensor(self.params, self.my_params)
+        else:
+            self._apply(self.my_params, self.my_grads, 1.0, bump=self.owns_step)
+
+    def describe(self):
+        return (f"async-rule dp{self.world}: all-to-all gradient push, per-worker unaveraged apply on the "
+                f"owning shard, all-gather pull" + (", hipGraph" if self.use_graph else ", eager"))
+
+
+def build_replica_trainer(mode: str, **kw):
+    cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
+           "async": AsyncAllToAllTrainer}[mode]
+    if mode == "single" and kw.get("world", 1) != 1:
+        raise ValueError("single mode is one process")
+    return cls(**kw)

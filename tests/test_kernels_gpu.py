@@ -1,0 +1,176 @@
+"""Every HIP kernel against a plain PyTorch fp32 oracle of the same op."""
+import pytest
+import torch
+
+from distributed_tensorflow_amd.models import MLPEngine
+from distributed_tensorflow_amd.ops import hip_backend as hb
+from distributed_tensorflow_amd.ops import reference as ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def test_library_loaded():
+    assert hb.available(), "libdtf_hip.so must be loadable on a GPU box"
+    assert "gfx950" in hb.build_info()
+
+
+@pytest.mark.parametrize("M,K,H", [(100, 784, 100), (10000, 784, 100), (1, 8, 1), (33, 50, 37), (128, 785, 130)])
+@pytest.mark.parametrize("act", [ref.ACT_SIGMOID, ref.ACT_RELU])
+def test_linear_bias_act(M, K, H, act):
+    x, W, b = _rand(M, K, seed=1), _rand(K, H, scale=0.1, seed=2), _rand(H, seed=3)
+    out = hb.linear_bias_act(x, W, b, act)
+    want = ref.linear_bias_act(x.double(), W.double(), b.double(), act).float()
+    torch.testing.assert_close(out, want, rtol=2e-5, atol=2e-5)
+
+
+def test_mfma_orientation_asymmetric():
+    # identity A with an asymmetric B exposes a transposed tile write
+    K = H = 64
+    x = torch.eye(K, device=DEV)
+    W = (torch.arange(K * H, device=DEV, dtype=torch.float32).reshape(K, H)) / (K * H)
+    out = hb.linear_bias_act(x, W, torch.zeros(H, device=DEV), ref.ACT_RELU)
+    torch.testing.assert_close(out, W)
+
+
+@pytest.mark.parametrize("ksplit", [2, 7, 13])
+def test_linear_splitk_atomic(ksplit):
+    x, W = _rand(100, 784, seed=4), _rand(784, 100, seed=5)
+    out = hb.linear_splitk(x, W, ksplit)
+    want = (x.double() @ W.double()).float()
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,K,H", [(100, 784, 100), (7, 33, 5), (600, 784, 100)])
+def test_dw_gemm_modes(M, K, H):
+    x, dz = _rand(M, K, seed=6), _rand(M, H, scale=0.01, seed=7)
+    want = (x.double().t() @ dz.double()).float()
+    got = hb.dw_gemm(x, dz, mode=0, scale=0.5)
+    torch.testing.assert_close(got, 0.5 * want, rtol=1e-4, atol=1e-5)
+    W = _rand(K, H, seed=8)
+    W0 = W.clone()
+    lr = torch.tensor([0.1], device=DEV)
+    hb.dw_gemm(x, dz, out=W, mode=1, lr=lr)
+    torch.testing.assert_close(W, W0 - 0.1 * want, rtol=1e-4, atol=1e-5)
+    acc = torch.ones(K, H, device=DEV)
+    hb.dw_gemm(x, dz, out=acc, mode=2)
+    torch.testing.assert_close(acc, 1.0 + want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [4, 79510, 1000003])
+def test_sgd_apply_and_accumulate(n):
+    p, g = _rand(n, seed=9), _rand(n, seed=10)
+    p0, g0 = p.clone(), g.clone()
+    lr = torch.tensor([0.25], device=DEV)
+    gs = torch.zeros(1, device=DEV)
+    hb.sgd_apply_(p, g, lr, scale=0.5, zero_grad=True, global_step=gs)
+    torch.testing.assert_close(p, p0 - 0.125 * g0)
+    assert float(g.abs().max()) == 0.0 and float(gs) == 1.0
+    acc = _rand(n, seed=11)
+    a0 = acc.clone()
+    hb.accumulate_(acc, g0)
+    torch.testing.assert_close(acc, a0 + g0)
+
+
+def test_philox_normal_matches_host_and_is_offset_consistent():
+    out = torch.empty(64, device=DEV)
+    hb.philox_normal_(out, seed=1, offset=0)
+    host = ref.philox_normal_host(64, seed=1)
+    torch.testing.assert_close(out.cpu(), host, rtol=1e-3, atol=1e-3)
+    part = torch.empty(13, device=DEV)
+    hb.philox_normal_(part, seed=1, offset=21)
+    torch.testing.assert_close(part, out[21:34])
+    big = torch.empty(784 * 100, device=DEV)
+    hb.philox_normal_(big, seed=1, offset=0, mean=0.0, stddev=1.0)
+    assert abs(float(big.mean())) < 0.02 and abs(float(big.std()) - 1.0) < 0.02
+
+
+def test_gather_rows():
+    src = _rand(1000, 784, seed=12)
+    idx = torch.randperm(1000).to(DEV)
+    torch.testing.assert_close(hb.gather_rows(src, idx), src[idx])
+    src2 = _rand(100, 10, seed=13)
+    idx2 = torch.randperm(100).to(DEV)
+    torch.testing.assert_close(hb.gather_rows(src2, idx2), src2[idx2])
+
+
+def _engine(device, B=100, K=784, H=100, C=10, act="sigmoid", with_grads=True, scale=0.1, nb=3):
+    g = torch.Generator().manual_seed(42)
+    p = {"W1": torch.randn(K, H, generator=g) * scale, "b1": torch.randn(H, generator=g) * scale,
+         "W2": torch.randn(H, C, generator=g), "b2": torch.randn(C, generator=g) * scale}
+    p = {k: v.to(device) for k, v in p.items()}
+    grads = {k: torch.zeros_like(v) for k, v in p.items()} if with_grads else None
+    gs = torch.zeros(1, device=device)
+    eng = MLPEngine(p, grads, batch=B, lr=0.05, act=act, global_step=gs, hist_cap=64)
+    x = torch.rand(nb * B, K, generator=g)
+    lab = torch.randint(0, C, (nb * B,), generator=g)
+    y = torch.nn.functional.one_hot(lab, C).float()
+    eng.bind_data(x.to(device), y.to(device))
+    return eng
+
+
+@pytest.mark.parametrize("B,K,H,C,act", [(100, 784, 100, 10, "sigmoid"), (100, 784, 100, 10, "relu"),
+                                         (37, 50, 24, 3, "sigmoid"), (128, 64, 128, 16, "relu"),
+                                         (300, 784, 100, 10, "sigmoid")])
+def test_step_grad_matches_reference(B, K, H, C, act):
+    eng = _engine(DEV, B, K, H, C, act)
+    eng.set_cursor(1)
+    eng.step_grad(bias=1, scale=0.5)
+    torch.cuda.synchronize()
+    xb, yb = eng.x[2 * B:3 * B].double(), eng.y[2 * B:3 * B].double()
+    want = ref.mlp_grads(xb, yb, *(eng.p[k].double() for k in ("W1", "b1", "W2", "b2")), eng.act)
+    for k in ("W1", "b1", "W2", "b2"):
+        torch.testing.assert_close(eng.g[k], 0.5 * want["d" + k].float(), rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    slot = 2 % eng.hist_cap
+    assert abs(float(eng.loss_hist[slot]) - float(want["loss"])) < 1e-4
+    assert abs(float(eng.acc_hist[slot]) - float(want["acc"])) < 1e-6
+    assert float(eng.z2.abs().max()) == 0.0, "split-K accumulator must be recycled to zero"
+
+
+def test_fused_steps_track_cpu_reference():
+    gpu = _engine(DEV, with_grads=False)
+    cpu = _engine("cpu", with_grads=False)
+    for e in (gpu, cpu):
+        e.run_chunk(3, use_graph=False)
+        e.run_chunk(2, use_graph=False)
+    for k in MLPEngine.PARAM_NAMES:
+        torch.testing.assert_close(gpu.p[k].cpu(), cpu.p[k], rtol=1e-4, atol=1e-5)
+    assert float(gpu.global_step) == 5.0 and int(gpu.cursor) == 5
+    torch.testing.assert_close(gpu.loss_hist[:5].cpu(), cpu.loss_hist[:5], rtol=1e-4, atol=1e-5)
+
+
+def test_graph_replay_equals_eager():
+    a = _engine(DEV, with_grads=False)
+    b = _engine(DEV, with_grads=False)
+    a.run_chunk(3, use_graph=True)
+    a.run_chunk(3, use_graph=True)
+    b.run_chunk(6, use_graph=False)
+    torch.cuda.synchronize()
+    for k in MLPEngine.PARAM_NAMES:
+        torch.testing.assert_close(a.p[k], b.p[k], rtol=1e-5, atol=1e-6)
+    assert int(a.cursor) == 6 and float(a.global_step) == 6.0
+
+
+def test_eval_matches_reference():
+    eng = _engine(DEV, with_grads=False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(10000, 784, generator=g).to(DEV)
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (10000,), generator=g), 10).float().to(DEV)
+    loss, acc = eng.evaluate(x, y)
+    wl, wa = ref.mlp_loss_acc(x.double(), y.double(), *(eng.p[k].double() for k in ("W1", "b1", "W2", "b2")), eng.act)
+    assert abs(loss - float(wl)) < 1e-3 * max(1.0, float(wl))
+    assert abs(acc - float(wa)) < 1e-4
+
+
+def test_log_zero_edge_case_is_finite():
+    # saturated logits: the reference's log(softmax) would produce -inf * 0 = NaN
+    eng = _engine(DEV, scale=1.0)
+    eng.p["W2"].mul_(200.0)
+    eng.step_grad()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.loss_hist[0]) and all(torch.isfinite(v).all() for v in eng.g.values())
