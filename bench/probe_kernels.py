@@ -1,0 +1,127 @@
+"""Per-kernel probes: event-timed launch loops and in-kernel phase stamps of the head kernel.
+
+    python bench/probe_kernels.py            (on the GPU box)
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.models import MLPEngine  # noqa: E402
+from distributed_tensorflow_amd.ops import hip_backend as hb  # noqa: E402
+
+
+def make_engine(B=100):
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(1)
+    p = {"W1": torch.randn(784, 100, generator=g), "b1": torch.zeros(100),
+         "W2": torch.randn(100, 10, generator=g), "b2": torch.zeros(10)}
+    p = {k: v.to(dev) for k, v in p.items()}
+    grads = {k: torch.zeros_like(v) for k, v in p.items()}
+    eng = MLPEngine(p, grads, batch=B, lr=0.001, global_step=torch.zeros(1, device=dev))
+    x = torch.rand(550 * B, 784, generator=g).to(dev)
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (550 * B,), generator=g), 10).float().to(dev)
+    eng.bind_data(x, y)
+    return eng
+
+
+def timed(fn, iters=300, warm=20):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / iters
+
+
+def main():
+    eng = make_engine()
+    lib = hb.require()
+    d = eng._descriptor()
+    x, W1, b1 = eng.x[:100], eng.p["W1"], eng.p["b1"]
+    z = torch.zeros(100, 100, device="cuda")
+    dz = torch.randn(100, 100, device="cuda") * 0.01
+    out = torch.zeros(784, 100, device="cuda")
+    empty = torch.zeros(1, device="cuda")
+    print("us per launch, graph-replayed back to back:")
+    print("  empty torch fill      %.2f" % timed(lambda: empty.zero_()))
+    for ks in (1, 4, 7, 13):
+        if ks == 1:
+            f = lambda: hb.linear_bias_act(x, W1, b1, 0, out=z)
+        else:
+            f = lambda ks=ks: hb.linear_splitk(x, W1, ks, out=z)
+        print("  fwd gemm ksplit=%-2d     %.2f" % (ks, timed(f)))
+    print("  dw gemm (store)       %.2f" % timed(lambda: hb.dw_gemm(x, dz, out=out, mode=0)))
+    print("  dw gemm (sgd)         %.2f" % timed(lambda: hb.dw_gemm(x, dz, out=out, mode=1, lr=eng.lr)))
+    hb.force_generic_path(True)
+    print("  step_grad (3 kernels) %.2f" % timed(lambda: hb.mlp_step_grad(d, 0, 0, 1.0)))
+    print("  step_fused(3 kernels) %.2f" % timed(lambda: hb.mlp_step_fused(d, 0, 0)))
+    hb.force_generic_path(False)
+    par = [0]
+
+    def alt(fn):
+        def run():
+            fn(par[0])
+            par[0] ^= 1
+        return run
+
+    print("  step_grad (2 kernels) %.2f" % timed(alt(lambda q: hb.mlp_step_grad(d, 0, q, 1.0)), iters=300, warm=20))
+    eng.zws.zero_(); par[0] = 0
+    print("  step_fused(2 kernels) %.2f" % timed(alt(lambda q: hb.mlp_step_fused(d, 0, q)), iters=300, warm=20))
+    eng.zws.zero_()
+    p = torch.zeros(79512, device="cuda")
+    gg = torch.zeros(79512, device="cuda")
+    print("  sgd_apply 79.5k       %.2f" % timed(lambda: hb.sgd_apply_(p, gg, eng.lr)))
+
+    stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+    lib.dtf_debug_set_head_stamps(stamps.data_ptr())
+    hb.force_generic_path(True)
+    for _ in range(3):
+        hb.mlp_step_fused(d, 0, 0)
+    torch.cuda.synchronize()
+    hb.force_generic_path(False)
+    lib.dtf_debug_set_head_stamps(None)
+    s = stamps.cpu().view(16, 2)
+    names = ["start", "loads issued", "small staged+sync", "a2 staged+sync", "phase1 logits/softmax",
+             "dW2 tiles (wave0)", "phase2 done+sync", "end"]
+    print("head kernel phases (thread 0): wall ns (100 MHz clock) / shader cycles")
+    for i in range(1, 8):
+        print("  %-24s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
+    print("  %-24s %7d ns %8d cyc" % ("total", (s[7, 0] - s[0, 0]) * 10, s[7, 1] - s[0, 1]))
+
+
+def bwd_stamps():
+    eng = make_engine()
+    lib = hb.require()
+    d = eng._descriptor()
+    stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+    lib.dtf_debug_set_bwd_stamps.argtypes = [C.c_void_p]
+    lib.dtf_debug_set_bwd_stamps.restype = None
+    lib.dtf_debug_set_bwd_stamps(stamps.data_ptr())
+    for _ in range(3):
+        hb.mlp_step_fused(d, 0, 0)
+    torch.cuda.synchronize()
+    lib.dtf_debug_set_bwd_stamps(None)
+    s = stamps.cpu().view(16, 2)
+    names = ["start", "loads issued", "staged+sync", "logits/softmax+sync", "dW1 mfma loop", "red write+sync",
+             "epilogue", "duties"]
+    print("bwd_all phases (last block, thread 0): wall ns / shader cycles")
+    for i in range(1, 8):
+        print("  %-24s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
+    print("  %-24s %7d ns %8d cyc" % ("total", (s[7, 0] - s[0, 0]) * 10, s[7, 1] - s[0, 1]))
+
+
+if __name__ == "__main__":
+    bwd_stamps()
+    main()

@@ -39,13 +39,17 @@ typedef struct DtfMlpDesc {
   float* loss_hist;           // ring of per-step mean loss (may be null)
   float* acc_hist;            // ring of per-step batch accuracy (may be null)
   float* global_step;         // device float scalar bumped by fused steps (may be null)
+  float* shadow;              // [H*C + C] workspace: read-side copy of W2/b2 for fused steps
+  float* zws;                 // [2][2048] zero-initialised logit ping-pong accumulators
 } DtfMlpDesc;
 
-// `bias` = position of this step inside a captured chunk (see dtf_common.h).
-// fwd + loss + bwd + in-place SGD in three launches.
-int dtf_mlp_step_fused(const DtfMlpDesc* d, int bias, void* stream);
+// `batch_index` = mini-batch of the resident set (added to *cursor when a
+// device cursor is used).  `parity` must alternate 0,1,0,1,... over consecutive
+// steps of one descriptor (it selects the logit accumulator half).
+// fwd + loss + bwd + in-place SGD; two launches for small batches, three otherwise.
+int dtf_mlp_step_fused(const DtfMlpDesc* d, int batch_index, int parity, void* stream);
 // fwd + loss + bwd writing gradients (scaled by grad_scale) to g*; no update.
-int dtf_mlp_step_grad(const DtfMlpDesc* d, int bias, float grad_scale, void* stream);
+int dtf_mlp_step_grad(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, void* stream);
 // cursor += n  (one thread).
 int dtf_advance_cursor(int32_t* cursor, int n, void* stream);
 

@@ -32,3 +32,8 @@ int dtf_launch_fwd_gemm(const float* xbase, const int* cursor, int bias, int bpe
 int dtf_launch_dw_gemm(const float* xbase, const int* cursor, int bias, int bpe, const float* dZ,
                        float* out, int M, int K, int H, int mode, float scale, const float* lr,
                        hipStream_t stream);
+
+struct DtfMlpDesc;
+bool dtf_step2_supported(int B, int K, int H, int C);
+int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
+                     hipStream_t stream);

@@ -11,6 +11,8 @@
 
 namespace {
 
+bool g_force_generic = false;   // tests/probes: run the generic three-launch path
+
 int check_desc(const DtfMlpDesc* d, bool need_grads) {
   if (!d) return DTF_ERR_NULL;
   if (d->in_dim <= 0 || d->hidden <= 0 || d->classes <= 0 || d->classes > 16 || d->batch <= 0)
@@ -31,8 +33,13 @@ __global__ void zero_hist_slot_kernel(const int* cursor, int bias, float* loss_h
   }
 }
 
-int run_step(const DtfMlpDesc* d, int bias, int head_mode, float grad_scale, hipStream_t stream) {
+int run_step(const DtfMlpDesc* d, int bias, int parity, int head_mode, float grad_scale, hipStream_t stream) {
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
+  // Small-batch fast path: two launches (see mlp_step2.hip).  It addresses the
+  // mini-batch by kernel argument, so it needs the cursor-free form.
+  if (!d->cursor && !g_force_generic && dtf_step2_supported(B, K, H, C) &&
+      d->zws && (head_mode != DTF_HEAD_FUSED || d->shadow))
+    return dtf_launch_step2(d, bias, parity, head_mode, grad_scale, stream);
   const int head_grid = dtf_head_grid(B, H);
   if (head_mode == DTF_HEAD_FUSED && head_grid != 1) return DTF_ERR_UNSUPPORTED;
 
@@ -92,16 +99,17 @@ int run_step(const DtfMlpDesc* d, int bias, int head_mode, float grad_scale, hip
 
 }  // namespace
 
-extern "C" int dtf_mlp_step_fused(const DtfMlpDesc* d, int bias, void* stream) {
+extern "C" int dtf_mlp_step_fused(const DtfMlpDesc* d, int batch_index, int parity, void* stream) {
   int rc = check_desc(d, false);
   if (rc) return rc;
-  return run_step(d, bias, DTF_HEAD_FUSED, 1.0f, (hipStream_t)stream);
+  return run_step(d, batch_index, parity, DTF_HEAD_FUSED, 1.0f, (hipStream_t)stream);
 }
 
-extern "C" int dtf_mlp_step_grad(const DtfMlpDesc* d, int bias, float grad_scale, void* stream) {
+extern "C" int dtf_mlp_step_grad(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale,
+                                 void* stream) {
   int rc = check_desc(d, true);
   if (rc) return rc;
-  return run_step(d, bias, DTF_HEAD_GRAD, grad_scale, (hipStream_t)stream);
+  return run_step(d, batch_index, parity, DTF_HEAD_GRAD, grad_scale, (hipStream_t)stream);
 }
 
 extern "C" int dtf_mlp_eval(const float* x, const float* y, int M, int K, int H, int C, int act,
@@ -128,3 +136,5 @@ extern "C" int dtf_mlp_eval(const float* x, const float* y, int M, int K, int H,
 extern "C" const char* dtf_hip_build_info(void) {
   return "libdtf_hip gfx950 fp32-mfma " __DATE__ " " __TIME__;
 }
+
+extern "C" void dtf_debug_force_generic_path(int on) { g_force_generic = on != 0; }

@@ -53,29 +53,65 @@ struct HeadParams {
   int hist_cap;
   float* global_step;
   int M, H, C, R, act, mode;
+  long long* stamps;     // optional in-kernel phase stamps (profiling builds of the caller)
 };
 
+// Phase stamp: {100 MHz wall clock, shader clock} written by thread 0 of block 0.
+#define DTF_STAMP(i)                                              \
+  do {                                                            \
+    if (p.stamps && threadIdx.x == 0 && blockIdx.x == 0) {        \
+      p.stamps[2 * (i)] = (long long)wall_clock64();              \
+      p.stamps[2 * (i) + 1] = (long long)clock64();               \
+    }                                                             \
+  } while (0)
+
+// 16-lane reductions on the DPP crossbar (a DPP "row" is exactly one 16-lane
+// MFMA column group): quad xor-1, quad xor-2, half-row mirror, row mirror.
+// Full-rate VALU moves instead of ds_bpermute round trips through the LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <-> 7-i within 8
+constexpr int kDppRowMirror = 0x140;  // lane i <-> 15-i within 16
+
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  v = fmaxf(v, dpp_f<kDppXor1>(v));
+  v = fmaxf(v, dpp_f<kDppXor2>(v));
+  v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+  v = fmaxf(v, dpp_f<kDppRowMirror>(v));
   return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+  v += dpp_f<kDppXor1>(v);
+  v += dpp_f<kDppXor2>(v);
+  v += dpp_f<kDppHalfMirror>(v);
+  v += dpp_f<kDppRowMirror>(v);
   return v;
 }
-// argmax with ties resolved to the smallest index (tf.argmax behaviour).
-__device__ __forceinline__ int group16_argmax(float v, int idx) {
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
-    const float ov = __shfl_xor(v, m);
-    const int oi = __shfl_xor(idx, m);
-    if (ov > v || (ov == v && oi < idx)) {
-      v = ov;
-      idx = oi;
-    }
+// argmax with ties resolved to the smallest index (tf.argmax behaviour).  The
+// comparison is a total order, so every lane of the group ends with the same pair.
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float& v, int& idx) {
+  const float ov = dpp_f<CTRL>(v);
+  const int oi = dpp_i<CTRL>(idx);
+  if (ov > v || (ov == v && oi < idx)) {
+    v = ov;
+    idx = oi;
   }
+}
+__device__ __forceinline__ int group16_argmax(float v, int idx) {
+  argmax_step<kDppXor1>(v, idx);
+  argmax_step<kDppXor2>(v, idx);
+  argmax_step<kDppHalfMirror>(v, idx);
+  argmax_step<kDppRowMirror>(v, idx);
   return idx;
 }
 // Sum over the four 16-lane groups of a wave (rows of one MFMA tile).
@@ -85,6 +121,11 @@ __device__ __forceinline__ float across_groups_sum(float v) {
   return v;
 }
 
+// The kernel makes exactly ONE global-memory round trip: every input (hidden
+// pre-activations, b1, W2, b2, labels, lr) is requested in phase 0 before any
+// of it is consumed; phases 1-3 read LDS only and end in fire-and-forget
+// global stores.  Updates in FUSED mode are computed from the LDS copies of the
+// parameters, never by re-reading global memory.
 __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int H16 = (p.H + 15) & ~15;
@@ -92,8 +133,11 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
   float* a2s = lds;                       // [R][lda]
   float* W2s = a2s + p.R * lda;           // [H16][kLdc]
   float* dz3s = W2s + H16 * kLdc;         // [R][kLdc]
-  float* db1s = dz3s + p.R * kLdc;        // [H16]
-  float* db2s = db1s + H16;               // [16]
+  float* ys = dz3s + p.R * kLdc;          // [R][16] labels
+  float* b1s = ys + p.R * kCP;            // [H16]
+  float* db1s = b1s + H16;                // [H16]
+  float* b2s = db1s + H16;                // [16]
+  float* db2s = b2s + 16;                 // [16]
   float* scal = db2s + 16;                // [0] loss sum, [1] correct count
 
   const int tid = threadIdx.x;
@@ -105,64 +149,128 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
   const int nrows = min(p.R, p.M - r0);
   const int H = p.H, C = p.C, R = p.R;
   const bool single = gridDim.x == 1;
+  const int row_tiles = R >> 4;
+  const int h_tiles = H16 >> 4;
 
-  // ---- phase 0: stage parameters and activations -------------------------
-  for (int e = tid; e < H16 * kCP; e += kThreads) {
+  DTF_STAMP(0);
+  // ---- phase 0: request everything, then stage into LDS ---------------------
+  const float lr = (p.mode == DTF_HEAD_FUSED) ? *p.lr : 0.f;
+  const float* __restrict__ Y =
+      p.ybase + dtf_batch_index(p.cursor, p.bias, p.batches_per_epoch) * (long)p.M * C;
+
+  // (a) hidden activations: wave w owns rows w, w+16, ...; lanes sweep columns.
+  constexpr int MAXR = 8;   // R <= 128 -> at most 8 rows per wave
+  constexpr int MAXC = 2;   // fast path: H16 <= 128 -> two 64-column passes
+  const bool fast = H16 <= 64 * MAXC;
+  float zreg[MAXR][MAXC];
+  if (fast) {
+#pragma unroll
+    for (int rr = 0; rr < MAXR; ++rr) {
+      const int row = wave + rr * kWaves;
+#pragma unroll
+      for (int cc = 0; cc < MAXC; ++cc) {
+        const int h = lane + cc * 64;
+        zreg[rr][cc] = (rr < row_tiles && row < nrows && h < H) ? p.zin[(long)(r0 + row) * H + h] : 0.f;
+      }
+    }
+  }
+  // (b) small operands
+  float w2reg[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kThreads;
+    const int h = e >> 4, c = e & 15;
+    w2reg[u] = (e < H16 * kCP && h < H && c < C) ? p.W2[h * C + c] : 0.f;
+  }
+  float yreg[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kThreads;
+    const int row = e >> 4, c = e & 15;
+    yreg[u] = (row < nrows && c < C) ? Y[(long)(r0 + row) * C + c] : 0.f;
+  }
+  const float b1reg = (tid < H && !p.pre_act) ? p.b1[tid] : 0.f;   // H <= 1024 here
+  const float b2reg = (tid < C) ? p.b2[tid] : 0.f;
+
+  DTF_STAMP(1);
+  // ---- everything requested; now consume -------------------------------------
+  if (tid < H16) {
+    b1s[tid] = b1reg;
+    db1s[tid] = 0.f;
+  }
+  if (tid < 16) {
+    b2s[tid] = b2reg;
+    db2s[tid] = 0.f;
+  }
+  if (tid < 2) scal[tid] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kThreads;
+    if (e < H16 * kCP) W2s[(e >> 4) * kLdc + (e & 15)] = w2reg[u];
+    if (e < R * kCP) ys[e] = yreg[u];
+  }
+  for (int e = tid + 2 * kThreads; e < H16 * kCP; e += kThreads) {  // H16 > 128 only
     const int h = e >> 4, c = e & 15;
     W2s[h * kLdc + c] = (h < H && c < C) ? p.W2[h * C + c] : 0.f;
   }
-  for (int e = tid; e < H16; e += kThreads) db1s[e] = 0.f;
-  if (tid < 16) db2s[tid] = 0.f;
-  if (tid < 2) scal[tid] = 0.f;
-  {
-    // Four independent loads per thread are issued before any of them is
-    // consumed, so the staging costs one global round trip, not twelve.
-    constexpr int U = 4;
-    const int total = R * H16;
-    for (int base = tid; base < total; base += kThreads * U) {
-      float z[U], bv[U];
-      int rowv[U], hv[U];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = base + u * kThreads;
-        rowv[u] = e / H16;
-        hv[u] = e - rowv[u] * H16;
-        ok[u] = e < total && rowv[u] < nrows && hv[u] < H;
-        z[u] = ok[u] ? p.zin[(long)(r0 + rowv[u]) * H + hv[u]] : 0.f;
-        bv[u] = (ok[u] && !p.pre_act) ? p.b1[hv[u]] : 0.f;
+  if (!fast) {
+    // generic (wide hidden layer) staging: bias is read from global directly
+    for (int rr = 0; rr < row_tiles; ++rr) {
+      const int row = wave + rr * kWaves;
+      for (int h = lane; h < H16; h += 64) {
+        float a = 0.f;
+        if (row < nrows && h < H) {
+          const float z = p.zin[(long)(r0 + row) * H + h];
+          a = p.pre_act ? z : dtf_act_fwd(z + p.b1[h], p.act);
+          if (p.zero_zin) p.zin[(long)(r0 + row) * H + h] = 0.f;
+        }
+        a2s[row * lda + h] = a;
       }
+    }
+  }
+  __syncthreads();   // b1s visible
+  DTF_STAMP(2);
+  if (fast) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = base + u * kThreads;
-        if (e < total) {
-          float a = 0.f;
-          if (ok[u]) {
-            a = p.pre_act ? z[u] : dtf_act_fwd(z[u] + bv[u], p.act);
-            if (p.zero_zin) p.zin[(long)(r0 + rowv[u]) * H + hv[u]] = 0.f;
+    for (int rr = 0; rr < MAXR; ++rr) {
+      const int row = wave + rr * kWaves;
+      if (rr < row_tiles) {
+#pragma unroll
+        for (int cc = 0; cc < MAXC; ++cc) {
+          const int h = lane + cc * 64;
+          if (h < H16) {
+            float a = 0.f;
+            if (row < nrows && h < H) {
+              a = p.pre_act ? zreg[rr][cc] : dtf_act_fwd(zreg[rr][cc] + b1s[h], p.act);
+              if (p.zero_zin) p.zin[(long)(r0 + row) * H + h] = 0.f;
+            }
+            a2s[row * lda + h] = a;
           }
-          a2s[rowv[u] * lda + hv[u]] = a;
         }
       }
     }
   }
   __syncthreads();
+  DTF_STAMP(3);
 
   // ---- phase 1: logits, softmax, loss, accuracy, dz3 ----------------------
-  const float* __restrict__ Y =
-      p.ybase + dtf_batch_index(p.cursor, p.bias, p.batches_per_epoch) * (long)p.M * C;
   const float inv_batch = 1.0f / (float)p.M;
-  const int row_tiles = R >> 4;
-  const int h_tiles = H16 >> 4;
   const int H4 = (H + 3) & ~3;
   for (int t = wave; t < row_tiles; t += kWaves) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // two accumulators break the MFMA dependency chain (40-cycle latency, 32-cycle issue)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float* arow = a2s + (t * 16 + i16) * lda + q;
     const float* brow = W2s + q * kLdc + i16;
-    for (int k = 0; k < H4; k += 4)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], brow[k * kLdc], acc, 0, 0, 0);
+    int k = 0;
+#pragma unroll 4
+    for (; k + 8 <= H4; k += 8) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], brow[k * kLdc], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k + 4], brow[(k + 4) * kLdc], acc1, 0, 0, 0);
+    }
+    if (k < H4) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k], brow[k * kLdc], acc0, 0, 0, 0);
+    const f32x4 acc = acc0 + acc1;
     const bool col_ok = i16 < C;
-    const float bias2 = col_ok ? p.b2[i16] : 0.f;
+    const float bias2 = b2s[i16];
     float colsum = 0.f, wloss = 0.f, wcorrect = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -175,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
       const float se = group16_sum(e);
       const float logp = z - mx - logf(se);
       const float prob = e / se;
-      const float y = (row_ok && col_ok) ? Y[(long)(r0 + row) * C + i16] : 0.f;
+      const float y = ys[row * kCP + i16];   // zero outside the valid rows/classes
       const float ysum = group16_sum(y);
       const float rloss = group16_sum(col_ok ? -y * logp : 0.f);
       const int az = group16_argmax(zm, i16);
@@ -201,6 +309,7 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
     }
   }
   __syncthreads();
+  DTF_STAMP(4);
 
   if (p.mode == DTF_HEAD_EVAL) {
     if (tid == 0) {
@@ -210,69 +319,94 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
     return;
   }
 
-  const float lr = (p.mode == DTF_HEAD_FUSED) ? *p.lr : 0.f;
   const float gs = p.grad_scale;
 
-  // ---- phase 2: dW2 tiles, then da2/dz2 tiles ------------------------------
+  // ---- phase 2: dW2 tiles (long: R/4 MFMAs) and da2/dz2 tiles (short) ---------
   const int n_dw = h_tiles;
   const int n_da = row_tiles * h_tiles;
   const int C4 = (C + 3) & ~3;
-  for (int item = wave; item < n_dw + n_da; item += kWaves) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (item < n_dw) {
-      // dW2[h][c] = sum_b a2[b][h] dz3[b][c]
-      const int th = item;
-      const float* arow = a2s + q * lda + th * 16 + i16;
-      const float* brow = dz3s + q * kLdc + i16;
-      for (int kb = 0; kb < R; kb += 4)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * lda], brow[kb * kLdc], acc, 0, 0, 0);
-      if (i16 < C) {
+
+  auto do_dw = [&](int th) {
+    // dW2[h][c] = sum_b a2[b][h] dz3[b][c]
+    const float* arow = a2s + q * lda + th * 16 + i16;
+    const float* brow = dz3s + q * kLdc + i16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int kb = 0;
+#pragma unroll 4
+    for (; kb + 8 <= R; kb += 8) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * lda], brow[kb * kLdc], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[(kb + 4) * lda], brow[(kb + 4) * kLdc], acc1, 0, 0, 0);
+    }
+    if (kb < R)
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * lda], brow[kb * kLdc], acc0, 0, 0, 0);
+    const f32x4 acc = acc0 + acc1;
+    if (i16 < C) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int h = th * 16 + q * 4 + g;
-          if (h < H) {
-            float* dst = p.oW2 + h * C + i16;
-            if (p.mode == DTF_HEAD_FUSED) {
-              *dst = *dst - lr * acc[g];
-            } else if (single) {
-              *dst = gs * acc[g];
-            } else {
-              atomicAdd(dst, gs * acc[g]);
-            }
+      for (int g = 0; g < 4; ++g) {
+        const int h = th * 16 + q * 4 + g;
+        if (h < H) {
+          float* dst = p.oW2 + h * C + i16;
+          if (p.mode == DTF_HEAD_FUSED) {
+            *dst = W2s[h * kLdc + i16] - lr * acc[g];
+          } else if (single) {
+            *dst = gs * acc[g];
+          } else {
+            atomicAdd(dst, gs * acc[g]);
           }
         }
       }
-    } else {
-      // da2[b][h] = sum_c dz3[b][c] W2[h][c];  dz2 = da2 * act'(a2)
-      const int it = item - n_dw;
-      const int tb = it / h_tiles, th = it - tb * h_tiles;
-      const float* arow = dz3s + (tb * 16 + i16) * kLdc + q;
-      const float* brow = W2s + (th * 16 + i16) * kLdc + q;
-      for (int kc = 0; kc < C4; kc += 4)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kc], brow[kc], acc, 0, 0, 0);
-      const int h = th * 16 + i16;
-      float csum = 0.f;
+    }
+  };
+  auto do_da = [&](int it) {
+    // da2[b][h] = sum_c dz3[b][c] W2[h][c];  dz2 = da2 * act'(a2)
+    const int tb = it / h_tiles, th = it - tb * h_tiles;
+    const float* arow = dz3s + (tb * 16 + i16) * kLdc + q;
+    const float* brow = W2s + (th * 16 + i16) * kLdc + q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kc = 0; kc < C4; kc += 4)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kc], brow[kc], acc, 0, 0, 0);
+    const int h = th * 16 + i16;
+    float csum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = tb * 16 + q * 4 + g;
-        const float a = a2s[row * lda + h];
-        const float dz = acc[g] * dtf_act_bwd(a, p.act);
-        if (row < nrows && h < H) {
-          p.dz2[(long)(r0 + row) * H + h] = dz;
-          csum += dz;
-        }
+    for (int g = 0; g < 4; ++g) {
+      const int row = tb * 16 + q * 4 + g;
+      const float a = a2s[row * lda + h];
+      const float dz = acc[g] * dtf_act_bwd(a, p.act);
+      if (row < nrows && h < H) {
+        p.dz2[(long)(r0 + row) * H + h] = dz;
+        csum += dz;
       }
-      csum = across_groups_sum(csum);
-      if (q == 0 && h < H) atomicAdd(&db1s[h], csum);
+    }
+    csum = across_groups_sum(csum);
+    if (q == 0 && h < H) atomicAdd(&db1s[h], csum);
+  };
+
+  // Waves that own a dW2 tile (about 3.5 da2-tiles of work) join only every
+  // fourth round of the da2 distribution, so all 16 waves finish together.
+  for (int th = wave; th < n_dw; th += kWaves) do_dw(th);
+  DTF_STAMP(5);
+  {
+    const int busy = n_dw < kWaves ? n_dw : kWaves;
+    const int n_free = kWaves - busy;
+    int base = 0;
+    for (int r = 0; base < n_da; ++r) {
+      const bool all = ((r & 3) == 3) || n_free == 0;
+      const int cnt = all ? kWaves : n_free;
+      const int my = all ? wave : wave - busy;
+      if (my >= 0 && base + my < n_da) do_da(base + my);
+      base += cnt;
     }
   }
   __syncthreads();
+  DTF_STAMP(6);
 
   // ---- phase 3: bias gradients / updates, bookkeeping ----------------------
   for (int h = tid; h < H; h += kThreads) {
     const float g = db1s[h];
     if (p.mode == DTF_HEAD_FUSED) {
-      p.ob1[h] = p.ob1[h] - lr * g;
+      // b1s holds the pre-update bias on the fast path
+      p.ob1[h] = (fast ? b1s[h] : p.ob1[h]) - lr * g;
     } else if (single) {
       p.ob1[h] = gs * g;
     } else {
@@ -282,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
   if (tid < C) {
     const float g = db2s[tid];
     if (p.mode == DTF_HEAD_FUSED) {
-      p.ob2[tid] = p.ob2[tid] - lr * g;
+      p.ob2[tid] = b2s[tid] - lr * g;
     } else if (single) {
       p.ob2[tid] = gs * g;
     } else {
@@ -305,11 +439,13 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadParams p) {
     }
     if (p.mode == DTF_HEAD_FUSED && p.global_step) *p.global_step = *p.global_step + 1.0f;
   }
+  DTF_STAMP(7);
 }
 
 size_t head_lds_bytes(int R, int H) {
   const int H16 = (H + 15) & ~15;
-  const size_t floats = (size_t)R * (H16 + 1) + (size_t)H16 * kLdc + (size_t)R * kLdc + H16 + 16 + 2;
+  const size_t floats = (size_t)R * (H16 + 1) + (size_t)H16 * kLdc + (size_t)R * kLdc + (size_t)R * kCP +
+                        2 * (size_t)H16 + 32 + 2;
   return floats * sizeof(float);
 }
 
@@ -323,6 +459,7 @@ int pick_rows(int M, int H) {
 }
 
 bool g_attr_set = false;
+long long* g_stamps = nullptr;   // device buffer of 16 {wall, cycle} pairs, or null
 
 }  // namespace
 
@@ -330,6 +467,7 @@ int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream) {
   if (!a.zin || !a.W2 || !a.b2 || !a.ybase) return DTF_ERR_NULL;
   if (!a.pre_act && !a.b1) return DTF_ERR_NULL;
   if (a.M <= 0 || a.H <= 0 || a.C <= 0 || a.C > kCP) return DTF_ERR_SHAPE;
+  if (a.H > 1024) return DTF_ERR_UNSUPPORTED;
   if (a.mode == DTF_HEAD_EVAL && (!a.loss_sum || !a.correct)) return DTF_ERR_NULL;
   if (a.mode != DTF_HEAD_EVAL && (!a.dz2 || !a.oW2 || !a.ob2 || !a.ob1)) return DTF_ERR_NULL;
   if (a.mode == DTF_HEAD_FUSED && !a.lr) return DTF_ERR_NULL;
@@ -354,6 +492,7 @@ int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream) {
   p.loss_hist = a.loss_hist; p.acc_hist = a.acc_hist; p.hist_cap = a.hist_cap;
   p.global_step = a.global_step;
   p.M = a.M; p.H = a.H; p.C = a.C; p.R = R; p.act = a.act; p.mode = a.mode;
+  p.stamps = g_stamps;
   hipLaunchKernelGGL(mlp_head_kernel, dim3(grid), dim3(kThreads), lds, stream, p);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
@@ -362,3 +501,7 @@ int dtf_head_grid(int M, int H) {
   const int R = pick_rows(M, H);
   return (M + R - 1) / R;
 }
+
+// Profiling hook: pass a device buffer of >= 32 int64 to have the next head
+// launches record {wall_clock64, clock64} at their phase boundaries; null disables.
+extern "C" void dtf_debug_set_head_stamps(long long* device_buffer) { g_stamps = device_buffer; }

@@ -13,9 +13,13 @@ three step flavours every training mode is built from:
   test pass, reference tfdist_between.py:109).
 
 The training set stays resident in HBM (55,000 x 784 fp32 = 172 MB of 288 GB),
-so a step needs no host->device copy; mini-batches are addressed through a
-device-side cursor, which lets any number of steps be captured into a single
-hipGraph and replayed with one host call (``run_chunk``).
+so a step needs no host->device copy.  The index of the mini-batch inside the
+epoch is a plain kernel argument, so a chunk of n steps starting at epoch
+position p is captured once into a hipGraph keyed by (p, n) and replayed every
+epoch with one host call (``run_chunk``); the resident set is reshuffled in
+place between epochs, which keeps those graphs valid.  (A device-side cursor
+would cost every kernel a dependent global load — about 1 us — before its first
+useful load.)
 
 On CPU tensors every method runs the PyTorch reference implementation with the
 same semantics, which is both the soft-placement fallback and the test oracle.
@@ -60,18 +64,23 @@ class MLPEngine:
             hb.require()
         dev = self.device
         self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
-        self.cursor = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.hist_cap = int(hist_cap)
         self.loss_hist = torch.zeros((self.hist_cap,), dtype=torch.float32, device=dev)
         self.acc_hist = torch.zeros((self.hist_cap,), dtype=torch.float32, device=dev)
         self.z2 = torch.zeros((self.B, self.H), dtype=torch.float32, device=dev)
         self.dz2 = torch.zeros((self.B, self.H), dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros((self.H * self.C + self.C,), dtype=torch.float32, device=dev)
+        # Logit ping-pong accumulators of the two-launch step.  Invariant: before a step
+        # that uses half `parity`, that half is all zeros; the step leaves it dirty and
+        # clears the other half, so consecutive steps alternate the parity.
+        self.zws = torch.zeros((2 * 2048,), dtype=torch.float32, device=dev)
+        self.parity = 0
         self.global_step = global_step
         self.ksplit = int(ksplit)
         self.x = None
         self.y = None
         self.batches_per_epoch = 0
-        self._host_cursor = 0  # CPU path only
+        self._host_cursor = 0  # mini-batches consumed so far
         self._desc = None
         self._graphs = {}
         self._eval_ws = None
@@ -100,7 +109,6 @@ class MLPEngine:
 
     def set_cursor(self, value: int):
         self._host_cursor = int(value)
-        self.cursor.fill_(int(value))
 
     def set_lr(self, lr: float):
         self.lr.fill_(float(lr))
@@ -127,22 +135,24 @@ class MLPEngine:
                     raise ValueError(f"gradient {k} must be contiguous and parameter-shaped")
                 setattr(d, "g" + k, gt.data_ptr())
         d.z2, d.dz2 = self.z2.data_ptr(), self.dz2.data_ptr()
-        d.cursor, d.lr = self.cursor.data_ptr(), self.lr.data_ptr()
+        d.cursor, d.lr = None, self.lr.data_ptr()
         d.loss_hist, d.acc_hist = self.loss_hist.data_ptr(), self.acc_hist.data_ptr()
         d.global_step = self.global_step.data_ptr() if self.global_step is not None else None
+        d.shadow = self.shadow.data_ptr()
+        d.zws = self.zws.data_ptr()
         self._desc = d
         return d
 
     # -- CPU reference path -----------------------------------------------------
-    def _cpu_batch(self, bias: int):
-        b = (self._host_cursor + bias) % self.batches_per_epoch
+    def _cpu_batch(self, batch_index: int):
+        b = batch_index % self.batches_per_epoch
         sl = slice(b * self.B, (b + 1) * self.B)
         return self.x[sl], self.y[sl]
 
-    def _cpu_step(self, bias: int, fused: bool, scale: float):
-        xb, yb = self._cpu_batch(bias)
+    def _cpu_step(self, batch_index: int, fused: bool, scale: float):
+        xb, yb = self._cpu_batch(batch_index)
         out = ref.mlp_grads(xb, yb, self.p["W1"], self.p["b1"], self.p["W2"], self.p["b2"], self.act)
-        slot = (self._host_cursor + bias) % self.hist_cap
+        slot = (batch_index % self.batches_per_epoch) % self.hist_cap
         self.loss_hist[slot] = out["loss"]
         self.acc_hist[slot] = out["acc"]
         lr = float(self.lr.item())
@@ -155,60 +165,69 @@ class MLPEngine:
             self.global_step.add_(1.0)
 
     # -- steps ----------------------------------------------------------------
-    def step_fused(self, bias: int = 0):
-        """One SGD step on batch (cursor + bias); does not move the cursor."""
-        if self.on_gpu:
-            hb.mlp_step_fused(self._descriptor(), bias)
-        else:
-            self._cpu_step(bias, True, 1.0)
+    def _bi(self, batch_index: Optional[int]) -> int:
+        if batch_index is None:
+            batch_index = self._host_cursor
+        return int(batch_index) % self.batches_per_epoch
 
-    def step_grad(self, bias: int = 0, scale: float = 1.0):
-        """Gradients of batch (cursor + bias) into the gradient tensors; no update."""
+    def step_fused(self, batch_index: Optional[int] = None):
+        """One SGD step on mini-batch ``batch_index`` of the epoch (default: the cursor's)."""
+        bi = self._bi(batch_index)
+        if self.on_gpu:
+            hb.mlp_step_fused(self._descriptor(), bi, self.parity)
+            self.parity ^= 1
+        else:
+            self._cpu_step(bi, True, 1.0)
+
+    def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0):
+        """Gradients of mini-batch ``batch_index`` into the gradient tensors; no update."""
         if self.g is None:
             raise RuntimeError("engine was built without gradient tensors")
+        bi = self._bi(batch_index)
         if self.on_gpu:
-            hb.mlp_step_grad(self._descriptor(), bias, scale)
+            hb.mlp_step_grad(self._descriptor(), bi, self.parity, scale)
+            self.parity ^= 1
         else:
-            self._cpu_step(bias, False, scale)
+            self._cpu_step(bi, False, scale)
 
     def advance(self, n: int = 1):
-        if self.on_gpu:
-            hb.advance_cursor(self.cursor, n)
-        else:
-            self.cursor.add_(n)
         self._host_cursor += n
 
     def run_chunk(self, n: int, use_graph: bool = True):
-        """``n`` fused steps on consecutive batches, then cursor += n.
+        """``n`` fused steps on consecutive batches starting at the cursor, then cursor += n.
 
-        On the GPU the 3n+1 launches are captured once per ``n`` into a hipGraph
-        and replayed; the host issues a single call per chunk.
+        On the GPU the 3n launches are captured once per (epoch position, n)
+        into a hipGraph and replayed; the host issues a single call per chunk.
         """
         if n <= 0:
             return
+        pos = self._host_cursor % self.batches_per_epoch
         if not self.on_gpu or not use_graph:
             for i in range(n):
-                self.step_fused(i)
+                self.step_fused(pos + i)
             self.advance(n)
             return
-        g = self._graphs.get(n)
+        key = (pos, n, self.parity)
+        g = self._graphs.get(key)
         if g is None:
-            g = self._capture(n)
-            self._graphs[n] = g
+            g = self._capture(pos, n)
+            self._graphs[key] = g
         g.replay()
+        self.parity ^= n & 1
         self._host_cursor += n
 
-    def _capture(self, n: int) -> "torch.cuda.CUDAGraph":
+    def _capture(self, pos: int, n: int) -> "torch.cuda.CUDAGraph":
         self._descriptor()
         # Warm up on a side stream (module load, attribute set) without
         # disturbing training state: snapshot and restore what a step mutates.
         saved = {k: v.clone() for k, v in self.p.items()}
         saved_gs = self.global_step.clone() if self.global_step is not None else None
         saved_hist = (self.loss_hist.clone(), self.acc_hist.clone())
+        parity0 = self.parity
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            self.step_fused(0)
+            self.step_fused(pos)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         for k, v in saved.items():
@@ -217,13 +236,18 @@ class MLPEngine:
             self.global_step.copy_(saved_gs)
         self.loss_hist.copy_(saved_hist[0])
         self.acc_hist.copy_(saved_hist[1])
+        self.reset_step_workspace(parity0)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for i in range(n):
-                hb.mlp_step_fused(self._desc, i)
-            hb.advance_cursor(self.cursor, n)
+                hb.mlp_step_fused(self._desc, (pos + i) % self.batches_per_epoch, parity0 ^ (i & 1))
         return graph
+
+    def reset_step_workspace(self, parity: int = 0):
+        """Re-establish the ping-pong invariant (after warm-up steps whose effects are rolled back)."""
+        self.zws.zero_()
+        self.parity = int(parity) & 1
 
     # -- evaluation ---------------------------------------------------------------
     def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
@@ -244,13 +268,20 @@ class MLPEngine:
         return float(loss_sum.item()) / M, float(correct.item()) / M
 
     # -- history --------------------------------------------------------------------
+    def _slot(self, step: int) -> int:
+        return (step % self.batches_per_epoch) % self.hist_cap
+
     def history(self, first_step: int, count: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Per-step (loss, batch accuracy) for steps [first_step, first_step+count) as CPU tensors."""
-        if count > self.hist_cap:
+        """Per-step (loss, batch accuracy) for steps [first_step, first_step+count) as CPU tensors.
+
+        The ring is indexed by position in the epoch, so a window must be read
+        before the same positions are trained on again.
+        """
+        if count > min(self.hist_cap, self.batches_per_epoch):
             raise ValueError("history window larger than the ring")
-        idx = (torch.arange(first_step, first_step + count) % self.hist_cap).to(self.device)
+        idx = torch.tensor([self._slot(s) for s in range(first_step, first_step + count)],
+                           dtype=torch.long, device=self.device)
         return self.loss_hist[idx].cpu(), self.acc_hist[idx].cpu()
 
     def last_loss(self) -> float:
-        slot = (self._host_cursor - 1) % self.hist_cap
-        return float(self.loss_hist[slot].item())
+        return float(self.loss_hist[self._slot(self._host_cursor - 1)].item())

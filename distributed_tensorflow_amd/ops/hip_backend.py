@@ -53,13 +53,15 @@ class DtfMlpDesc(C.Structure):
         ("loss_hist", C.c_void_p),
         ("acc_hist", C.c_void_p),
         ("global_step", C.c_void_p),
+        ("shadow", C.c_void_p),
+        ("zws", C.c_void_p),
     ]
 
 
 def _declare(lib: C.CDLL) -> None:
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
-    lib.dtf_mlp_step_fused.argtypes = [C.POINTER(DtfMlpDesc), i32, vp]
-    lib.dtf_mlp_step_grad.argtypes = [C.POINTER(DtfMlpDesc), i32, f32, vp]
+    lib.dtf_mlp_step_fused.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, vp]
+    lib.dtf_mlp_step_grad.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, vp]
     lib.dtf_advance_cursor.argtypes = [vp, i32, vp]
     lib.dtf_mlp_eval.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dtf_linear_bias_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -69,6 +71,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_philox_normal.argtypes = [vp, i64, u64, u64, f32, f32, vp]
     lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.dtf_hip_build_info.restype = C.c_char_p
+    lib.dtf_debug_force_generic_path.argtypes = [i32]
+    lib.dtf_debug_force_generic_path.restype = None
+    lib.dtf_debug_set_head_stamps.argtypes = [vp]
+    lib.dtf_debug_set_head_stamps.restype = None
     for name in ("dtf_mlp_step_fused", "dtf_mlp_step_grad", "dtf_advance_cursor", "dtf_mlp_eval",
                  "dtf_linear_bias_act", "dtf_dw_gemm", "dtf_sgd_apply", "dtf_accumulate",
                  "dtf_philox_normal", "dtf_gather_rows"):
@@ -229,13 +235,14 @@ def mlp_eval(x, y, W1, b1, W2, b2, act: int, a2_ws, loss_sum, correct):
                             _ptr(a2_ws), _ptr(loss_sum), _ptr(correct), _stream()), "dtf_mlp_eval")
 
 
-def mlp_step_fused(desc: DtfMlpDesc, bias: int = 0):
-    _check(require().dtf_mlp_step_fused(C.byref(desc), int(bias), _stream()), "dtf_mlp_step_fused")
+def mlp_step_fused(desc: DtfMlpDesc, batch_index: int, parity: int):
+    _check(require().dtf_mlp_step_fused(C.byref(desc), int(batch_index), int(parity), _stream()),
+           "dtf_mlp_step_fused")
 
 
-def mlp_step_grad(desc: DtfMlpDesc, bias: int = 0, grad_scale: float = 1.0):
-    _check(require().dtf_mlp_step_grad(C.byref(desc), int(bias), float(grad_scale), _stream()),
-           "dtf_mlp_step_grad")
+def mlp_step_grad(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float = 1.0):
+    _check(require().dtf_mlp_step_grad(C.byref(desc), int(batch_index), int(parity), float(grad_scale),
+                                       _stream()), "dtf_mlp_step_grad")
 
 
 def advance_cursor(cursor: torch.Tensor, n: int):
@@ -245,3 +252,8 @@ def advance_cursor(cursor: torch.Tensor, n: int):
 def build_info() -> str:
     lib = load()
     return lib.dtf_hip_build_info().decode() if lib is not None else "unavailable"
+
+
+def force_generic_path(on: bool):
+    """Route steps through the generic three-launch kernels even where the two-launch path applies."""
+    require().dtf_debug_force_generic_path(1 if on else 0)

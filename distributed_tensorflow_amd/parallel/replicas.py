@@ -66,7 +66,7 @@ class _BaseTrainer:
         self._graphs = {}
 
     # -- to be provided ---------------------------------------------------------
-    def _one_step(self, bias: int):
+    def _one_step(self, batch_index: int):
         raise NotImplementedError
 
     def describe(self) -> str:
@@ -88,29 +88,36 @@ class _BaseTrainer:
         """Capture every chunk graph the hinted run_steps() calls will need, outside any timed region."""
         if not self.use_graph:
             return
+        bpe = self.engine.batches_per_epoch
         cursor = self.engine._host_cursor
-        sizes = set()
+        parity = self.engine.parity
+        keys = set()
         for n in steps_hint:
-            sizes.update(self._schedule(cursor, n))
-            cursor += n
-        for n in sorted(sizes):
-            self._get_graph(n)
+            for k in self._schedule(cursor, n):
+                keys.add((cursor % bpe, k, parity))
+                cursor += k
+                parity ^= k & 1
+        live = self.engine.parity
+        for pos, k, par in sorted(keys):
+            self._get_graph(pos, k, par)
+        self.engine.reset_step_workspace(live)
 
-    def _run_eager(self, n: int):
+    def _run_eager(self, pos: int, n: int):
         for i in range(n):
-            self._one_step(i)
+            self._one_step(pos + i)
         self.engine.advance(n)
 
-    def _get_graph(self, n: int):
-        g = self._graphs.get(n)
+    def _get_graph(self, pos: int, n: int, parity: int):
+        key = (pos, n, parity)
+        g = self._graphs.get(key)
         if g is None:
-            g = self._capture(n)
-            self._graphs[n] = g
+            g = self._capture(pos, n, parity)
+            self._graphs[key] = g
         return g
 
     def _snapshot(self):
         return (self.params.clone(), None if self.grads is None else self.grads.clone(),
-                self.engine.loss_hist.clone(), self.engine.acc_hist.clone(), self.engine.cursor.clone())
+                self.engine.loss_hist.clone(), self.engine.acc_hist.clone())
 
     def _restore(self, snap):
         self.params.copy_(snap[0])
@@ -118,9 +125,8 @@ class _BaseTrainer:
             self.grads.copy_(snap[1])
         self.engine.loss_hist.copy_(snap[2])
         self.engine.acc_hist.copy_(snap[3])
-        self.engine.cursor.copy_(snap[4])
 
-    def _capture(self, n: int):
+    def _capture(self, pos: int, n: int, parity: int):
         # Eager warm-up on a side stream (lazy module loads, communicator set-up),
         # with the training state restored afterwards.
         snap = self._snapshot()
@@ -128,16 +134,17 @@ class _BaseTrainer:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                self._one_step(0)
+                self._one_step(pos)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._restore(snap)
+        self.engine.reset_step_workspace(parity)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for i in range(n):
-                self._one_step(i)
-            hb.advance_cursor(self.engine.cursor, n)
+                self._one_step(pos + i)     # the engine flips its parity per step
+        self.engine.parity = parity         # capture did not execute anything
         return graph
 
     def run_steps(self, n: int):
@@ -148,10 +155,11 @@ class _BaseTrainer:
             if cur % bpe == 0 and cur > 0:
                 self.ds.shuffle_epoch()
             if self.use_graph:
-                self._get_graph(k).replay()
+                self._get_graph(cur % bpe, k, self.engine.parity).replay()
+                self.engine.parity ^= k & 1
                 self.engine._host_cursor += k
             else:
-                self._run_eager(k)
+                self._run_eager(cur % bpe, k)
             self.steps_done += k
 
     def evaluate(self, x, y):
@@ -174,8 +182,8 @@ class SingleTrainer(_BaseTrainer):
         self.engine.global_step = self.global_step
         self.engine._desc = None
 
-    def _one_step(self, bias: int):
-        self.engine.step_fused(bias)
+    def _one_step(self, batch_index: int):
+        self.engine.step_fused(batch_index)
 
     def describe(self):
         return "single (no PS): 3 fused kernels/step, hipGraph chunks of %d" % self.chunk if self.use_graph \
@@ -209,10 +217,10 @@ class _CollectiveTrainer(_BaseTrainer):
 class SyncShardTrainer(_CollectiveTrainer):
     name = "sync"
 
-    def _one_step(self, bias: int):
+    def _one_step(self, batch_index: int):
         d = self.dist
         # gradients pre-scaled by 1/N so that the reduce-scatter SUM is the mean
-        self.engine.step_grad(bias, scale=1.0 / self.world)
+        self.engine.step_grad(batch_index, scale=1.0 / self.world)
         if self.world > 1:
             d.reduce_scatter_tensor(self.my_grads, self.grads, op=d.ReduceOp.SUM)
         self._apply(self.my_params, self.my_grads, 1.0, bump=self.owns_step)
@@ -227,9 +235,9 @@ class SyncShardTrainer(_CollectiveTrainer):
 class TowerTrainer(_CollectiveTrainer):
     name = "towers"
 
-    def _one_step(self, bias: int):
+    def _one_step(self, batch_index: int):
         d = self.dist
-        self.engine.step_grad(bias, scale=1.0 / self.world)
+        self.engine.step_grad(batch_index, scale=1.0 / self.world)
         if self.world > 1:
             d.all_reduce(self.grads, op=d.ReduceOp.SUM)
         self._apply(self.params, self.grads, 1.0, bump=True)
@@ -249,9 +257,9 @@ class AsyncAllToAllTrainer(_CollectiveTrainer):
         n = self.layout.shard_numel(self.rank)
         self.inbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
 
-    def _one_step(self, bias: int):
+    def _one_step(self, batch_index: int):
         d = self.dist
-        self.engine.step_grad(bias, scale=1.0)
+        self.engine.step_grad(batch_index, scale=1.0)
         if self.world > 1:
             d.all_to_all_single(self.inbox.view(-1), self.grads)
             for w in range(self.world):   # N separate unaveraged applies, N global_step bumps
