@@ -1,0 +1,216 @@
+"""Shared body of the five training scripts at the repository root.
+
+Builds the reference's graph (names, creation order and placement as in
+tfdist_between.py:37-75) through the framework's TF-style API and runs the
+reference's training loop with its exact stdout contract
+(tfdist_between.py:86-112)::
+
+    Step: %d,  Epoch: %2d,  Batch: %3d of %3d,  Cost: %.4f,  AvgTime: %3.2fms
+    Test-Accuracy: %2.2f
+    Total Time: %3.2fs
+    Final Cost: %.4f
+
+Two execution tiers produce those lines:
+
+* ``run_session_loop``  — one ``sess.run`` per batch with a NumPy feed, a cost
+  fetch and an event-file write per step, like the reference;
+* ``run_resident_loop`` — the device-resident tier: the training split lives in
+  HBM, ``freq`` steps are replayed from one hipGraph, the host reads the cost
+  only when a progress line is due, and the per-step (cost, accuracy) summaries
+  are flushed to the event file in bulk.  Same model, same updates, same log.
+"""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+
+import distributed_tensorflow_amd as tf
+from distributed_tensorflow_amd.data import DeviceDataset, read_data_sets
+
+
+def define_hparam_flags():
+    f = tf.app.flags
+    f.DEFINE_integer("batch_size", 100, "mini-batch size per worker")
+    f.DEFINE_float("lr", 0.001, "SGD learning rate")
+    f.DEFINE_integer("epochs", 100, "passes over the training split")
+    f.DEFINE_string("logs_path", "./logs", "directory of the TensorBoard event files")
+    f.DEFINE_integer("freq", 100, "progress line every this many batches")
+    f.DEFINE_string("data_dir", "MNIST_data", "idx files if present, else synthetic MNIST-shaped data")
+    f.DEFINE_integer("train_size", 55000, "rows of the training split (synthetic data only)")
+    f.DEFINE_string("logdir", "", "checkpoint directory (empty: no checkpoints, like the reference)")
+    f.DEFINE_float("save_model_secs", 600, "checkpoint period of the chief")
+    f.DEFINE_string("activation", "sigmoid", "hidden activation: sigmoid (reference) or relu")
+    f.DEFINE_boolean("resident", False, "device-resident hipGraph loop instead of one sess.run per batch")
+    f.DEFINE_boolean("summaries", True, "write cost/accuracy summaries every step")
+    f.DEFINE_integer("max_steps", 0, "stop after this many batches in total (0: run all epochs)")
+    f.DEFINE_string("transport", "tcp", "parameter-server transport: tcp | ipc")
+
+
+def load_data(flags):
+    sizes = (int(flags.train_size), 5000, 10000) if int(flags.train_size) == 55000 else \
+        (int(flags.train_size), max(100, int(flags.train_size) // 11), max(1000, int(flags.train_size) // 5))
+    return read_data_sets(flags.data_dir, one_hot=True, sizes=sizes)
+
+
+def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0):
+    """The reference graph; call inside the ``tf.device(...)`` scope that places it."""
+    global_step = tf.get_variable("global_step", [], initializer=tf.constant_initializer(0), trainable=False)
+    with tf.name_scope("input"):
+        x = tf.placeholder(tf.float32, shape=[None, 784], name="x-input")
+        y_ = tf.placeholder(tf.float32, shape=[None, 10], name="y-input")
+    tf.set_random_seed(1)
+    with tf.name_scope("weights"):
+        W1 = tf.Variable(tf.random_normal([784, 100]))
+        W2 = tf.Variable(tf.random_normal([100, 10]))
+    with tf.name_scope("biases"):
+        b1 = tf.Variable(tf.zeros([100]))
+        b2 = tf.Variable(tf.zeros([10]))
+    act = tf.nn.relu if activation == "relu" else tf.nn.sigmoid
+    with tf.name_scope("softmax"):
+        a2 = act(tf.add(tf.matmul(x, W1), b1))
+        y = tf.nn.softmax(tf.add(tf.matmul(a2, W2), b2))
+    with tf.name_scope("cross_entropy"):
+        cross_entropy = tf.reduce_mean(-tf.reduce_sum(y_ * tf.log(y), reduction_indices=[1]))
+    with tf.name_scope("train"):
+        opt = tf.train.GradientDescentOptimizer(lr)
+        sync_opt = None
+        if sync_replicas:
+            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=sync_replicas,
+                                                      total_num_replicas=sync_replicas, use_locking=True)
+            train_op = sync_opt.minimize(cross_entropy, global_step=global_step)
+        else:
+            train_op = opt.minimize(cross_entropy, global_step=global_step)
+    with tf.name_scope("Accuracy"):
+        correct = tf.equal(tf.argmax(y, 1), tf.argmax(y_, 1))
+        accuracy = tf.reduce_mean(tf.cast(correct, tf.float32))
+    tf.summary.scalar("cost", cross_entropy)
+    tf.summary.scalar("accuracy", accuracy)
+    return SimpleNamespace(global_step=global_step, x=x, y_=y_, W1=W1, W2=W2, b1=b1, b2=b2, y=y,
+                           cross_entropy=cross_entropy, train_op=train_op, accuracy=accuracy,
+                           summary_op=tf.summary.merge_all(), init_op=tf.global_variables_initializer(),
+                           sync_opt=sync_opt)
+
+
+def progress_line(step, epoch, i, batch_count, cost, elapsed, freq) -> str:
+    # elapsed is always divided by freq, also for the shorter last window (tfdist_between.py:100-105)
+    return ("Step: %d,  Epoch: %2d,  Batch: %3d of %3d,  Cost: %.4f,  AvgTime: %3.2fms"
+            % (step + 1, epoch + 1, i + 1, batch_count, cost, float(elapsed * 1000 / freq)))
+
+
+def run_session_loop(sess, m, mnist, flags, writer=None, begin_time: Optional[float] = None) -> dict:
+    """One ``sess.run`` per batch — the reference's loop."""
+    begin_time = begin_time or time.time()
+    freq, batch_size = int(flags.freq), int(flags.batch_size)
+    start_time = time.time()
+    total, cost, acc, epoch_times = 0, float("nan"), float("nan"), []
+    fetches = [m.train_op, m.cross_entropy, m.summary_op if flags.summaries else None, m.global_step]
+    for epoch in range(int(flags.epochs)):
+        batch_count = int(mnist.train.num_examples / batch_size)
+        count = 0
+        for i in range(batch_count):
+            batch_x, batch_y = mnist.train.next_batch(batch_size)
+            _, cost, summary, step = sess.run(fetches, feed_dict={m.x: batch_x, m.y_: batch_y})
+            if writer is not None and summary is not None:
+                writer.add_summary(summary, step)
+            count += 1
+            total += 1
+            if count % freq == 0 or i + 1 == batch_count:
+                elapsed = time.time() - start_time
+                start_time = time.time()
+                print(progress_line(step, epoch, i, batch_count, cost, elapsed, freq), flush=True)
+                count = 0
+            if flags.max_steps and total >= int(flags.max_steps):
+                break
+        acc = sess.run(m.accuracy, feed_dict={m.x: mnist.test.images, m.y_: mnist.test.labels})
+        print("Test-Accuracy: %2.2f" % acc)
+        epoch_times.append(time.time() - begin_time)
+        print("Total Time: %3.2fs" % float(epoch_times[-1]))
+        begin_time = time.time()
+        print("Final Cost: %.4f" % cost, flush=True)
+        if flags.max_steps and total >= int(flags.max_steps):
+            break
+    return {"steps": total, "final_cost": float(cost), "test_accuracy": float(acc), "epoch_times": epoch_times}
+
+
+def run_resident_loop(trainer, mnist, flags, writer=None, begin_time: Optional[float] = None,
+                      step_of=lambda trainer: trainer.global_step_value()) -> dict:
+    """Device-resident tier driven by a ``parallel.replicas`` trainer; same stdout contract."""
+    import torch
+
+    begin_time = begin_time or time.time()
+    freq, batch_size = int(flags.freq), int(flags.batch_size)
+    dev = trainer.device
+    test_x = torch.as_tensor(mnist.test.images).to(dev)
+    test_y = torch.as_tensor(mnist.test.labels).to(dev)
+    batch_count = trainer.engine.batches_per_epoch
+    start_time = time.time()
+    total, cost, acc, epoch_times = 0, float("nan"), float("nan"), []
+    for epoch in range(int(flags.epochs)):
+        i = 0
+        while i < batch_count:
+            k = min(freq, batch_count - i)
+            if flags.max_steps:
+                k = min(k, int(flags.max_steps) - total)
+            first = trainer.engine._host_cursor
+            trainer.run_steps(k)
+            i += k
+            total += k
+            cost = trainer.last_loss()          # the only host sync of the window
+            step = step_of(trainer) - 1          # value a fetch in the last run of the window would have seen
+            if writer is not None and flags.summaries:
+                losses, accs = trainer.engine.history(first, k)
+                steps = np.arange(step - k + 1, step + 1)
+                writer.add_scalar_series(steps, ["cost", "accuracy"], np.stack([losses.numpy(), accs.numpy()], 1))
+            elapsed = time.time() - start_time
+            start_time = time.time()
+            print(progress_line(step, epoch, i - 1, batch_count, cost, elapsed, freq), flush=True)
+            if flags.max_steps and total >= int(flags.max_steps):
+                break
+        _, acc = trainer.evaluate(test_x, test_y)
+        print("Test-Accuracy: %2.2f" % acc)
+        epoch_times.append(time.time() - begin_time)
+        print("Total Time: %3.2fs" % float(epoch_times[-1]))
+        begin_time = time.time()
+        print("Final Cost: %.4f" % cost, flush=True)
+        if flags.max_steps and total >= int(flags.max_steps):
+            break
+    return {"steps": total, "final_cost": float(cost), "test_accuracy": float(acc), "epoch_times": epoch_times}
+
+
+def make_config(flags) -> "tf.ConfigProto":
+    config = tf.ConfigProto(allow_soft_placement=True, log_device_placement=True)
+    config.gpu_options.allow_growth = True
+    config.transport = getattr(flags, "transport", "tcp")
+    return config
+
+
+def run_worker(server, cluster, flags, sync: bool) -> dict:
+    """Between-graph worker: own graph, own session, variables on the PS shards."""
+    mnist = load_data(flags)
+    n_workers = cluster.num_tasks("worker")
+    with tf.device(tf.train.replica_device_setter(
+            worker_device="/job:worker/task:%d/gpu:%d" % (flags.task_index, flags.task_index), cluster=cluster)):
+        m = build_model(flags.lr, flags.activation, sync_replicas=n_workers if sync else 0)
+        print("Ready to go")
+    is_chief = flags.task_index == 0
+    sv = tf.train.Supervisor(is_chief=is_chief, global_step=m.global_step, init_op=m.init_op,
+                             logdir=flags.logdir or None, save_model_secs=flags.save_model_secs)
+    begin_time = time.time()
+    chief_queue_runner = m.sync_opt.get_chief_queue_runner() if sync else None
+    with sv.prepare_or_wait_for_session(server.target) as sess:
+        if sync and is_chief:
+            sv.start_queue_runners(sess, [chief_queue_runner])
+        writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
+        result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
+        if writer is not None:
+            writer.close()
+        if sync and is_chief:
+            sv.request_stop()
+        result["global_step"] = sess.store.global_step()
+        result["fused_steps"] = sess.fused_steps
+    sv.stop()
+    print("Done")
+    return result

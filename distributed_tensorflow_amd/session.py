@@ -1,0 +1,535 @@
+"""``Session``: executes fetches against a variable store.
+
+``Session(config=...)`` is the single-process form (reference tfsingle.py:67-68);
+``Session(server.target)`` — normally obtained from
+``Supervisor.prepare_or_wait_for_session`` — binds to the task's ``Server`` and
+keeps the variables on the parameter-server shards (reference
+tfdist_between.py:83, 93-95).
+
+``run(fetches, feed_dict)`` per call:
+
+1. **pull**: a distributed session copies every shard into the worker's local
+   slab (the Recv of W1, b1, W2, b2 and global_step of the reference's step);
+2. a **train op** among the fetches computes loss and gradients on the worker
+   device — through the fused HIP pipeline when the loss is the reference's
+   MLP pattern (:func:`match_mlp`), otherwise op by op with PyTorch autograd —
+   then **pushes**: in place (local), server-side SGD per shard (async), or
+   accumulate + wait for a token (SyncReplicas);
+3. remaining fetches are evaluated with the values of that same forward pass,
+   i.e. *before* the update, like TensorFlow's single ``sess.run``.
+
+The per-step host round trip of this API (feed, fetch of the cost) is what the
+reference pays too; the device-resident fast tier (``parallel.replicas``,
+``train.loop``) removes it.
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import graph as G
+from .cluster import ConfigProto, lookup_server
+from .models.mlp import MLPEngine
+from .ops import hip_backend as hb
+from .optim import Optimizer, SyncReplicasOptimizer
+from .parallel.store import LocalVariableStore, RemoteVariableStore
+from .placement import DeviceSpec, placement_report
+from .summary import Summary
+from .variables import ShardLayout
+
+_TORCH_DTYPES = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "int64": torch.int64,
+                 "bool": torch.bool}
+
+_session_stack: List["Session"] = []
+
+
+def get_default_session() -> Optional["Session"]:
+    return _session_stack[-1] if _session_stack else None
+
+
+# ---------------------------------------------------------------------------
+# pattern matching: the reference's model, loss and accuracy
+# ---------------------------------------------------------------------------
+
+def _is(node, op):
+    return isinstance(node, G.Tensor) and node.op == op
+
+
+def _linear(node):
+    """add(matmul(x, W), b) -> (x, W, b)"""
+    if not _is(node, "add"):
+        return None
+    for mm, b in (node.inputs, node.inputs[::-1]):
+        if _is(mm, "matmul") and isinstance(b, G.Variable) and not mm.attrs["transpose_a"] \
+                and not mm.attrs["transpose_b"] and isinstance(mm.inputs[1], G.Variable):
+            return mm.inputs[0], mm.inputs[1], b
+    return None
+
+
+def match_mlp(loss) -> Optional[Dict[str, Any]]:
+    """Recognise  mean(-sum(y_ * log(softmax(act(x W1 + b1) W2 + b2)), 1))  (tfdist_between.py:55-62)
+    or mean(softmax_cross_entropy_with_logits(labels=y_, logits=...))."""
+    if not _is(loss, "reduce_mean"):
+        return None
+    inner = loss.inputs[0]
+    y_ = probs = logits = None
+    if _is(inner, "softmax_xent"):
+        y_, logits = inner.inputs
+    elif _is(inner, "neg") and _is(inner.inputs[0], "reduce_sum") and inner.inputs[0].attrs["axis"] in ((1,), (-1,)):
+        prod = inner.inputs[0].inputs[0]
+        if not _is(prod, "mul"):
+            return None
+        for a, b in (prod.inputs, prod.inputs[::-1]):
+            if _is(b, "log") and _is(b.inputs[0], "softmax"):
+                y_, probs = a, b.inputs[0]
+                logits = probs.inputs[0]
+        if logits is None:
+            return None
+    else:
+        return None
+    l2 = _linear(logits)
+    if l2 is None:
+        return None
+    a2, W2, b2 = l2
+    if a2.op not in ("sigmoid", "relu"):
+        return None
+    l1 = _linear(a2.inputs[0])
+    if l1 is None:
+        return None
+    x, W1, b1 = l1
+    if not (_is(x, "placeholder") and _is(y_, "placeholder")):
+        return None
+    if len(W1.shape) != 2 or len(W2.shape) != 2 or W2.shape[1] > 16 or len(b1.shape) != 1 or len(b2.shape) != 1:
+        return None
+    return {"x": x, "y_": y_, "W1": W1, "b1": b1, "W2": W2, "b2": b2, "act": a2.op, "logits": logits,
+            "probs": probs, "loss": loss, "hidden": a2}
+
+
+def match_accuracy(node, m) -> bool:
+    """mean(cast(equal(argmax(y, 1), argmax(y_, 1)), float32))  (tfdist_between.py:68-70)"""
+    if not _is(node, "reduce_mean") or not _is(node.inputs[0], "cast"):
+        return False
+    eq = node.inputs[0].inputs[0]
+    if not _is(eq, "equal"):
+        return False
+    a, b = eq.inputs
+    if not (_is(a, "argmax") and _is(b, "argmax") and a.attrs["axis"] in (1, -1) and b.attrs["axis"] in (1, -1)):
+        return False
+    srcs = {a.inputs[0], b.inputs[0]}
+    return m["y_"] in srcs and (m["probs"] in srcs or m["logits"] in srcs)
+
+
+# ---------------------------------------------------------------------------
+class Session:
+    def __init__(self, target: str = "", graph: Optional[G.Graph] = None, config: Optional[ConfigProto] = None):
+        self.graph = graph or G.get_default_graph()
+        self.server = lookup_server(target) if target else None
+        if target and self.server is None:
+            raise ValueError(f"unknown session target {target!r}: create the task's Server first")
+        self.config = config or (self.server.config if self.server else ConfigProto())
+        self.device = self._resolve_device()
+        specs = [v.spec for v in self.graph.variables]
+        n_shards = self.server.num_ps if (self.server and self.server.num_ps > 0) else 1
+        if n_shards == 1:
+            for s in specs:
+                s.shard = 0
+        self.layout = ShardLayout(specs, n_shards, mode="by_variable")
+        if self.server is not None and self.server.num_ps > 0:
+            self.store = self._make_remote_store()
+            self.theta = self.layout.new_slab(self.device)
+        else:
+            self.store = LocalVariableStore(self.layout, self.device)
+            self.theta = self.store.bind_local()
+        self.grad = self.layout.new_slab(self.device)
+        self._engines: Dict[Any, MLPEngine] = {}
+        self._plans: Dict[int, Any] = {}
+        self._closed = False
+        self.fused_steps = 0
+        self.generic_steps = 0
+        if self.config.log_device_placement:
+            self._log_placement()
+
+    def _make_remote_store(self):
+        if self.config.transport == "ipc":
+            from .parallel.ps_ipc import IpcVariableStore
+
+            return IpcVariableStore(self.layout, self.server, self.device)
+        return RemoteVariableStore(self.layout, self.server, self.device)
+
+    # -- device -----------------------------------------------------------------
+    def _resolve_device(self) -> torch.device:
+        if self.server is not None:
+            return self.server.device
+        want_gpu, idx = None, 0
+        for n in self.graph.nodes:
+            d = DeviceSpec.from_string(n.device)
+            if d.device_type:
+                want_gpu, idx = d.device_type == "gpu", d.device_index or 0
+                break
+        if want_gpu is False:
+            return torch.device("cpu")
+        if torch.cuda.is_available():
+            return torch.device("cuda", idx % torch.cuda.device_count())
+        if want_gpu and not self.config.allow_soft_placement:
+            raise RuntimeError("graph requests /gpu:%d but no GPU is visible and allow_soft_placement=False" % idx)
+        return torch.device("cpu")
+
+    def _log_placement(self):
+        print("Device mapping:", flush=True)
+        for v in self.graph.variables:
+            where = v.device or f"/job:localhost/{self.device}"
+            print(f"{v.op_name}: (VariableV2): {where}", flush=True)
+        worker = None
+        for n in self.graph.nodes:
+            if n.op not in ("variable", "const") and n.device:
+                worker = n.device
+                break
+        print(f"<compute ops>: {worker or '/job:localhost'} -> {self.device}", flush=True)
+        print(self.layout.describe(), flush=True)
+
+    # -- context ------------------------------------------------------------------
+    def __enter__(self):
+        _session_stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        if _session_stack and _session_stack[-1] is self:
+            _session_stack.pop()
+        self.close()
+        return False
+
+    def as_default(self):
+        return self
+
+    def close(self):
+        if not self._closed:
+            self.store.close()
+            self._closed = True
+
+    # -- variables ------------------------------------------------------------------
+    def var_tensor(self, v: G.Variable) -> torch.Tensor:
+        return self.layout.view(self.theta, v.op_name)
+
+    def _pull(self):
+        self.store.pull(self.theta)
+
+    def _run_init(self, variables: Sequence[G.Variable]):
+        seed = self.graph.seed if self.graph.seed is not None else int(time.time())
+        all_vars = len(variables) == len(self.graph.variables)
+        self.store.initialize(seed, None if all_vars else [v.op_name for v in variables])
+        if self.store.is_remote:
+            self._pull()
+
+    # -- evaluation -------------------------------------------------------------------
+    def run(self, fetches, feed_dict: Optional[Dict[G.Tensor, Any]] = None, options=None, run_metadata=None):
+        if self._closed:
+            raise RuntimeError("session is closed")
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        feed = {}
+        for k, v in (feed_dict or {}).items():
+            feed[k] = v
+        cache: Dict[G.Tensor, Any] = {}
+        needs_vars = any(self._reads_variables(f) for f in flist if isinstance(f, G.Tensor))
+        if needs_vars and self.store.is_remote:
+            self._pull()
+        # train ops first: they define the forward pass the other fetches see.  Variables fetched
+        # in the same call (global_step) are read BEFORE the update — the reference prints
+        # step+1 for that reason (tfdist_between.py:102).
+        if any(_is(f, "train") for f in flist):
+            for f in flist:
+                if _is(f, "variable"):
+                    cache[f] = self.var_tensor(f).clone()
+        for f in flist:
+            if _is(f, "train"):
+                self._run_train(f, feed, cache)
+        out = []
+        for f in flist:
+            out.append(self._fetch(f, feed, cache))
+        return out[0] if single else out
+
+    def _reads_variables(self, node: G.Tensor, _seen=None) -> bool:
+        if node.op in ("variable", "train"):
+            return True
+        if node.op in ("init_all", "init_vars", "no_op", "sync_init_tokens"):
+            return False
+        key = ("rv", node)
+        if key in self._plans:
+            return self._plans[key]
+        r = any(self._reads_variables(i) for i in node.inputs)
+        if node.op in ("merge_summary", "scalar_summary", "gradient"):
+            r = True
+        self._plans[key] = r
+        return r
+
+    def _fetch(self, f, feed, cache):
+        if f is None:
+            return None
+        if not isinstance(f, G.Tensor):
+            raise TypeError(f"cannot fetch {f!r}")
+        if f.op in ("train", "init_all", "init_vars", "no_op", "group", "sync_init_tokens"):
+            if f.op in ("init_all", "init_vars"):
+                self._run_init(f.attrs["variables"])
+            elif f.op == "group":
+                for i in f.inputs:
+                    self._fetch(i, feed, cache)
+            elif f.op == "sync_init_tokens":
+                self._init_tokens(f)
+            return None
+        # whole-batch evaluation of the matched loss / accuracy on the fused kernels
+        fused = self._try_fused_eval(f, feed, cache)
+        if fused is not None:
+            return fused
+        v = self._eval(f, feed, cache)
+        return self._to_host(v)
+
+    @staticmethod
+    def _to_host(v):
+        if isinstance(v, torch.Tensor):
+            a = v.detach().cpu().numpy()
+            return a.item() if a.ndim == 0 else a
+        return v
+
+    def _feed_tensor(self, node, feed):
+        if node not in feed:
+            raise ValueError(f"placeholder {node.name} must be fed")
+        val = feed[node]
+        if isinstance(val, torch.Tensor):
+            return val.to(self.device, _TORCH_DTYPES[node.dtype])
+        return torch.as_tensor(np.asarray(val), dtype=_TORCH_DTYPES[node.dtype]).to(self.device)
+
+    def _eval(self, node: G.Tensor, feed, cache, var_override=None):
+        if node in cache:
+            return cache[node]
+        op = node.op
+        ins = node.inputs
+        ev = lambda n: self._eval(n, feed, cache, var_override)  # noqa: E731
+        if op == "variable":
+            r = var_override[node] if (var_override and node in var_override) else self.var_tensor(node)
+        elif op == "placeholder":
+            r = self._feed_tensor(node, feed)
+        elif op == "const":
+            r = torch.as_tensor(node.attrs["value"]).to(self.device)
+        elif op == "random_normal":
+            g = torch.Generator().manual_seed(int(node.attrs["seed"] or self.graph.seed or 0) + node.id)
+            r = (torch.randn(node.attrs["shape"], generator=g) * node.attrs["stddev"] + node.attrs["mean"]).to(self.device)
+        elif op == "zeros":
+            r = torch.zeros(node.attrs["shape"], device=self.device)
+        elif op == "ones":
+            r = torch.ones(node.attrs["shape"], device=self.device)
+        elif op == "matmul":
+            a, b = ev(ins[0]), ev(ins[1])
+            if node.attrs["transpose_a"]:
+                a = a.t()
+            if node.attrs["transpose_b"]:
+                b = b.t()
+            r = a @ b
+        elif op == "add":
+            r = ev(ins[0]) + ev(ins[1])
+        elif op == "sub":
+            r = ev(ins[0]) - ev(ins[1])
+        elif op == "mul":
+            r = ev(ins[0]) * ev(ins[1])
+        elif op == "div":
+            r = ev(ins[0]) / ev(ins[1])
+        elif op == "maximum":
+            r = torch.maximum(ev(ins[0]), ev(ins[1]))
+        elif op == "minimum":
+            r = torch.minimum(ev(ins[0]), ev(ins[1]))
+        elif op == "equal":
+            r = ev(ins[0]) == ev(ins[1])
+        elif op == "greater":
+            r = ev(ins[0]) > ev(ins[1])
+        elif op == "less":
+            r = ev(ins[0]) < ev(ins[1])
+        elif op == "neg":
+            r = -ev(ins[0])
+        elif op == "log":
+            r = torch.log(ev(ins[0]))
+        elif op == "exp":
+            r = torch.exp(ev(ins[0]))
+        elif op == "sqrt":
+            r = torch.sqrt(ev(ins[0]))
+        elif op == "square":
+            r = ev(ins[0]) ** 2
+        elif op == "abs":
+            r = ev(ins[0]).abs()
+        elif op == "sigmoid":
+            r = torch.sigmoid(ev(ins[0]))
+        elif op == "tanh":
+            r = torch.tanh(ev(ins[0]))
+        elif op == "relu":
+            r = torch.relu(ev(ins[0]))
+        elif op in ("identity",):
+            r = ev(ins[0])
+        elif op == "stop_gradient":
+            r = ev(ins[0]).detach()
+        elif op == "softmax":
+            r = torch.softmax(ev(ins[0]), dim=node.attrs["axis"])
+        elif op == "log_softmax":
+            r = torch.log_softmax(ev(ins[0]), dim=node.attrs["axis"])
+        elif op == "softmax_xent":
+            labels, logits = ev(ins[0]), ev(ins[1])
+            r = -(labels * torch.log_softmax(logits, dim=-1)).sum(dim=-1)
+        elif op in ("reduce_sum", "reduce_mean", "reduce_max"):
+            x = ev(ins[0])
+            ax, kd = node.attrs["axis"], node.attrs["keep_dims"]
+            if op == "reduce_sum":
+                r = x.sum() if ax is None else x.sum(dim=ax, keepdim=kd)
+            elif op == "reduce_mean":
+                x = x if x.is_floating_point() else x.float()
+                r = x.mean() if ax is None else x.mean(dim=ax, keepdim=kd)
+            else:
+                r = x.max() if ax is None else x.amax(dim=ax, keepdim=kd)
+        elif op == "argmax":
+            r = ev(ins[0]).argmax(dim=node.attrs["axis"])
+        elif op == "cast":
+            r = ev(ins[0]).to(_TORCH_DTYPES[node.attrs["dtype"]])
+        elif op == "reshape":
+            r = ev(ins[0]).reshape(node.attrs["shape"])
+        elif op == "transpose":
+            x = ev(ins[0])
+            r = x.permute(*node.attrs["perm"]) if node.attrs["perm"] else x.t()
+        elif op == "scalar_summary":
+            r = Summary([(node.attrs["tag"], float(ev(ins[0])))])
+        elif op == "merge_summary":
+            vals = []
+            for i in ins:
+                vals.extend(ev(i).values)
+            r = Summary(vals)
+        elif op in ("assign", "assign_add"):
+            val = ev(ins[1])
+            if self.store.is_remote:
+                raise NotImplementedError("assign on parameter-server variables: use an optimizer or Saver.restore")
+            dst = self.var_tensor(ins[0])
+            dst.copy_(val) if op == "assign" else dst.add_(val)
+            r = dst
+        elif op == "gradient":
+            loss, var = ins[0], node.attrs["wrt"]
+            leaf = self.var_tensor(var).detach().clone().requires_grad_(True)
+            val = self._eval(loss, feed, {}, {var: leaf})
+            (r,) = torch.autograd.grad(val, [leaf], allow_unused=True)
+            if r is None:
+                r = torch.zeros_like(leaf)
+        else:
+            raise NotImplementedError(f"op {op!r} ({node.name})")
+        cache[node] = r
+        return r
+
+    # -- training ------------------------------------------------------------------------
+    def _engine_for(self, m, batch: int) -> MLPEngine:
+        key = (id(m["loss"]), batch)
+        eng = self._engines.get(key)
+        if eng is None:
+            names = {r: m[r].op_name for r in ("W1", "b1", "W2", "b2")}
+            params = {r: self.layout.view(self.theta, n) for r, n in names.items()}
+            grads = {r: self.layout.view(self.grad, n) for r, n in names.items()}
+            eng = MLPEngine(params, grads, batch=batch, lr=0.0, act=m["act"], hist_cap=1)
+            K, C = params["W1"].shape[0], params["W2"].shape[1]
+            eng._x_stage = torch.zeros((batch, K), dtype=torch.float32, device=self.device)
+            eng._y_stage = torch.zeros((batch, C), dtype=torch.float32, device=self.device)
+            eng.bind_data(eng._x_stage, eng._y_stage, batches_per_epoch=1)
+            self._engines[key] = eng
+        return eng
+
+    def _stage(self, eng: MLPEngine, m, feed):
+        x, y = feed.get(m["x"]), feed.get(m["y_"])
+        if x is None or y is None:
+            raise ValueError("both input placeholders must be fed")
+        xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        yt = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+        eng._x_stage.copy_(xt, non_blocking=True)
+        eng._y_stage.copy_(yt, non_blocking=True)
+
+    def _plan(self, train_op):
+        plan = self._plans.get(id(train_op))
+        if plan is None:
+            loss = train_op.attrs["loss"]
+            m = match_mlp(loss) if loss is not None else None
+            if m is not None:
+                wanted = {m[r] for r in ("W1", "b1", "W2", "b2")}
+                if set(train_op.attrs["var_list"]) != wanted:
+                    m = None   # custom var_list: take the generic path
+            acc_nodes = [n for n in self.graph.nodes if m is not None and match_accuracy(n, m)]
+            plan = {"mlp": m, "acc_nodes": acc_nodes}
+            self._plans[id(train_op)] = plan
+        return plan
+
+    def _run_train(self, train_op, feed, cache):
+        opt: Optimizer = train_op.attrs["optimizer"]
+        plan = self._plan(train_op)
+        m = plan["mlp"]
+        lr = opt.lr_value()
+        sync = isinstance(opt, SyncReplicasOptimizer) and self.store.is_remote
+        if m is not None and m["x"] in feed:
+            xv = feed[m["x"]]
+            batch = int(xv.shape[0])
+            eng = self._engine_for(m, batch)
+            self._stage(eng, m, feed)
+            eng.step_grad(0, 1.0)
+            cache[m["loss"]] = eng.loss_hist[0].clone()
+            cache[("acc", id(m["loss"]))] = eng.acc_hist[0].clone()
+            for n in plan["acc_nodes"]:
+                cache[n] = cache[("acc", id(m["loss"]))]
+            self.fused_steps += 1
+        else:
+            self.grad.zero_()
+            var_list = train_op.attrs["var_list"]
+            leaves = {v: self.var_tensor(v).detach().clone().requires_grad_(True) for v in var_list}
+            fcache: Dict[G.Tensor, Any] = {}
+            loss_val = self._eval(train_op.attrs["loss"], feed, fcache, leaves)
+            grads = torch.autograd.grad(loss_val, [leaves[v] for v in var_list], allow_unused=True)
+            for v, g in zip(var_list, grads):
+                if g is not None:
+                    self.layout.view(self.grad, v.op_name).copy_(g)
+            for k, val in fcache.items():   # forward values seen by the other fetches
+                cache[k] = val.detach() if isinstance(val, torch.Tensor) else val
+            self.generic_steps += 1
+        # ---- push ----
+        if sync:
+            self.store.push_accumulate(self.grad)
+            self.store.dequeue_token()
+        elif isinstance(opt, SyncReplicasOptimizer):
+            # one local replica: aggregate of one
+            self.store.push_apply(self.grad, lr, True, bump_step=train_op.attrs["global_step"] is not None)
+        else:
+            self.store.push_apply(self.grad, lr, opt.use_locking, bump_step=train_op.attrs["global_step"] is not None)
+
+    def _init_tokens(self, node):
+        opt = node.attrs["optimizer"]
+        if self.store.is_remote:
+            clients = [self.server.client("ps", k) for k in range(self.store.n)]
+            self.store.enqueue_tokens(clients, self.store.global_step(), node.attrs["num_tokens"])
+
+    def _try_fused_eval(self, f, feed, cache):
+        """Loss / accuracy of the matched model over a fed batch, on the fused forward kernels."""
+        for plan in list(self._plans.values()):
+            if not isinstance(plan, dict) or plan.get("mlp") is None:
+                continue
+            m = plan["mlp"]
+            is_loss = f is m["loss"]
+            is_acc = (not is_loss) and match_accuracy(f, m)
+            if not (is_loss or is_acc):
+                continue
+            if is_loss and f in cache:
+                return float(cache[f])
+            if is_acc and ("acc", id(m["loss"])) in cache:
+                return float(cache[("acc", id(m["loss"]))])
+            if m["x"] not in feed or m["y_"] not in feed:
+                return None
+            if self.device.type != "cuda":
+                return None
+            x = torch.as_tensor(np.ascontiguousarray(feed[m["x"]], dtype=np.float32)).to(self.device)
+            y = torch.as_tensor(np.ascontiguousarray(feed[m["y_"]], dtype=np.float32)).to(self.device)
+            eng = self._engine_for(m, 1)
+            loss, acc = eng.evaluate(x, y)
+            cache[m["loss"]] = torch.tensor(loss)
+            cache[("acc", id(m["loss"]))] = torch.tensor(acc)
+            return loss if is_loss else acc
+        return None
+
+
+InteractiveSession = Session
