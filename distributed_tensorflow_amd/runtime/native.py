@@ -319,7 +319,7 @@ def write_bundle(prefix: str, tensors: List[Tuple[str, np.ndarray]]):
     """Write ``<prefix>.index`` and ``<prefix>.data-00000-of-00001`` (float32 tensors)."""
     h = lib().dtf_bundle_begin(str(prefix).encode())
     for name, arr in tensors:
-        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        arr = np.asarray(arr, dtype=np.float32, order="C")     # keeps 0-d scalars 0-d
         shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
         st = lib().dtf_bundle_add_f32(h, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim)
         if st != OK:

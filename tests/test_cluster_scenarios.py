@@ -1,0 +1,68 @@
+"""Multi-process integration: the README experiment matrix on a fake localhost cluster, few steps each.
+
+scenario 1: 1 PS + 1 worker async      scenario 2/3: 1 PS + 2 workers async
+scenario 4: 1 PS + 2 workers sync      scenario 5: 2 PS + 2 workers async     scenario 6: 2 PS + 2 workers sync
+"""
+import re
+
+import pytest
+
+from cluster_utils import launch_script
+
+ARGS = ["--epochs=1", "--train_size=1100", "--batch_size=100", "--freq=5", "--lr=0.01", "--nosummaries"]
+STEP_RE = re.compile(r"Step: (\d+),  Epoch: +(\d+),  Batch: +(\d+) of +(\d+),  Cost: ([\d.]+),  AvgTime: [\d.]+ms")
+
+
+def _check_worker(out):
+    assert "worker setting up ..." in out and "Ready to go" in out and out.rstrip().endswith("Done"), out[-2000:]
+    lines = STEP_RE.findall(out)
+    assert len(lines) == 3                                   # 11 batches, freq 5 -> batches 5, 10, 11
+    assert [int(l[2]) for l in lines] == [5, 10, 11] and all(int(l[3]) == 11 for l in lines)
+    assert re.search(r"Test-Accuracy: \d\.\d\d\n", out) and re.search(r"Total Time: [\d.]+s\n", out)
+    assert re.search(r"Final Cost: [\d.]+\n", out)
+    return [int(l[0]) for l in lines], [float(l[4]) for l in lines]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("script,n_ps,n_w", [
+    ("tfdist_between.py", 1, 1),
+    ("tfdist_between.py", 1, 2),
+    ("tfdist_between_sync.py", 1, 2),
+    ("tfdist_between.py", 2, 2),
+    ("tfdist_between_sync.py", 2, 2),
+])
+def test_readme_scenario(script, n_ps, n_w, tmp_path):
+    res = launch_script(script, n_ps, n_w, ARGS + [f"--logs_path={tmp_path}"])
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    for i in range(n_ps):
+        assert "ps setting up ..." in res[f"ps{i}"][1]       # and the PS left join() by itself
+    finals = []
+    for i in range(n_w):
+        steps, costs = _check_worker(res[f"worker{i}"][1])
+        finals.append(steps[-1])
+    if "sync" in script:
+        assert finals == [11] * n_w                         # one update per N worker batches
+    else:
+        assert max(finals) == 11 * n_w                      # every push is an update
+    if n_ps == 2:
+        out = res["worker0"][1]                             # log_device_placement shows the round-robin shards
+        assert "weights/Variable: (VariableV2): /job:ps/task:1" in out
+        assert "weights/Variable_1: (VariableV2): /job:ps/task:0" in out
+
+
+@pytest.mark.slow
+def test_single_process_script_both_tiers(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    from cluster_utils import ROOT
+
+    for extra in ([], ["--resident"]):
+        p = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tfsingle.py"), *ARGS[:-1], f"--logs_path={tmp_path}",
+                            *extra], cwd=ROOT, capture_output=True, text=True, timeout=240)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        steps, costs = _check_worker(p.stdout)
+        assert steps == [5, 10, 11]
+    assert any(f.startswith("events.out.tfevents.") for f in os.listdir(tmp_path))
