@@ -144,7 +144,12 @@ class Server:
         """Block like ``tf.train.Server.join``; returns True once the cluster asked this task to exit."""
         if self._native is None:
             self.start()
-        done = self._native.wait(timeout)
+        if self.job_name == "ps" and self.config.transport == "ipc" and timeout is None:
+            from .parallel.ps_ipc import serve_ipc_shard
+
+            done = serve_ipc_shard(self)      # allocates the GPU-resident shard on request, then waits
+        else:
+            done = self._native.wait(timeout)
         self._joined = True
         return done
 

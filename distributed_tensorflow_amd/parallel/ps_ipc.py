@@ -1,0 +1,276 @@
+"""GPU-resident parameter-server shards shared over HIP-IPC (one node).
+
+``ConfigProto(transport="ipc")``.  The ps task allocates its shard in the HBM of
+its GPU and exports the allocation as an IPC memory handle; workers map it and
+from then on move **no tensor bytes through any server**:
+
+* pull         one device-to-device copy per shard (same GPU, or peer-to-peer
+               over xGMI when the shard lives on another GPU) on the worker's
+               stream;
+* async push   the worker launches the sharded SGD kernel directly on the
+               mapped shard (``p -= lr*g`` written through the mapping): a
+               one-sided, lock-free Hogwild update, the meaning of
+               ``use_locking=False`` in the reference (tfdist_between.py:65);
+               ``use_locking=True`` brackets the launch with a mutex kept by the
+               ps task's native server;
+* sync push    the worker copies its gradient into ITS mailbox row next to the
+               shard (no atomics, no write conflicts), synchronises its stream
+               and reports arrival to the ps control plane together with its
+               ``local_step`` (stale gradients are refused there); the chief
+               aggregator waits for ``replicas_to_aggregate`` arrivals, applies
+               ``p -= lr/N * sum(mailboxes)`` with N SGD launches on its own
+               stream, bumps ``global_step`` and releases the tokens.
+
+This is the path for tasks that share a GPU — RCCL refuses two ranks on one
+device — e.g. "1 PS + 1 worker on one MI355X" and the reference's scenario of a
+PS and two workers on gpu0 (README.md:42-86), and it is the truly asynchronous
+data plane: no worker ever waits for a matching receive.
+
+Only the control plane (allocation request, handle exchange, arrival counters,
+tokens, locks) uses the native task servers.
+"""
+from __future__ import annotations
+
+import pickle
+import struct
+import threading
+import time
+from typing import List, Optional
+
+import torch
+
+from ..ops import hip_backend as hb
+from ..variables import ShardLayout
+from .store import INIT_KEY, TOKEN_Q
+
+ALLOC_KEY = "__ipc_alloc__"
+HANDLE_KEY = "__ipc_handle__"
+ARRIVALS = "__ipc_arrivals__"
+ACC_STEP = "__ipc_acc_step__"
+LOCK_Q = "__ipc_lock__"
+
+
+def _export(t: torch.Tensor) -> bytes:
+    from torch.multiprocessing.reductions import reduce_tensor
+
+    return pickle.dumps(reduce_tensor(t))
+
+
+def _import(blob: bytes) -> torch.Tensor:
+    fn, args = pickle.loads(blob)   # produced by _export() in the ps task of the same job
+    return fn(*args)
+
+
+def serve_ipc_shard(server, poll: float = 0.2) -> bool:
+    """Body of ``Server.join()`` for a ps task under the ipc transport.
+
+    Waits for the chief's allocation request ({numel, rows}), allocates
+    ``rows x numel`` floats on this task's GPU (row 0 = the variables, rows 1..N
+    = one gradient mailbox per worker), publishes the IPC handle and then
+    blocks until the cluster releases the task.  The tensor stays alive for the
+    lifetime of the process, which keeps the mapping valid in the workers.
+    """
+    from ..runtime import native as rt
+
+    me = rt.StoreClient("127.0.0.1", server.port, timeout=30)
+    keep = []
+    try:
+        while True:
+            if server._native.wait(0.0):
+                return True
+            try:
+                req = me.get(ALLOC_KEY, timeout=poll)
+            except TimeoutError:
+                continue
+            numel, rows = struct.unpack("<qq", req)
+            dev = server.device
+            if dev.type != "cuda":
+                raise RuntimeError("transport='ipc' needs a GPU in the ps task")
+            slab = torch.zeros((rows, max(numel, 4)), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
+            keep.append(slab)
+            me.qpush(LOCK_Q, b"1")                 # the shard mutex starts released
+            me.set(HANDLE_KEY, _export(slab))
+            me.delete(ALLOC_KEY)
+            if server.config.log_device_placement:
+                print(f"[ps {server.task_index}] shard of {numel} floats + {rows - 1} mailboxes resident on {dev}",
+                      flush=True)
+            return server._native.wait(None)
+    finally:
+        me.close()
+
+
+class IpcVariableStore:
+    is_remote = True
+
+    def __init__(self, layout: ShardLayout, server, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("transport='ipc' needs GPU workers")
+        hb.require()
+        self.layout = layout
+        self.server = server
+        self.device = device
+        self.n = layout.num_shards
+        self.n_workers = server.num_workers
+        self.widx = server.task_index
+        self.timeout = server.config.operation_timeout_in_ms / 1000.0
+        self.local_step = 0
+        self.dropped = 0
+        self._maps: List[Optional[torch.Tensor]] = [None] * self.n
+        self._gs_shard = layout.owner_of("global_step") if "global_step" in layout.var_range else 0
+        o, _ = layout.var_range.get("global_step", (0, 1))
+        self._gs_off = o - layout.shard_range[self._gs_shard][0]
+        self._lr_t = torch.zeros(1, dtype=torch.float32, device=device)
+        self._lr_val = None
+        self._agg_round = 0
+
+    def _c(self, k: int):
+        return self.server.client("ps", k)
+
+    def _lr(self, lr: float) -> torch.Tensor:
+        if self._lr_val != lr:
+            self._lr_t.fill_(float(lr))
+            self._lr_val = lr
+        return self._lr_t
+
+    # -- mapping ---------------------------------------------------------------------
+    def _map(self, k: int) -> torch.Tensor:
+        m = self._maps[k]
+        if m is None:
+            blob = self._c(k).get(HANDLE_KEY, timeout=self.timeout)
+            m = _import(blob)
+            self._maps[k] = m
+        return m
+
+    def _params(self, k: int) -> torch.Tensor:
+        return self._map(k)[0, :self.layout.shard_numel(k)] if self.layout.shard_numel(k) else self._map(k)[0, :0]
+
+    def _mailbox(self, k: int, worker: int) -> torch.Tensor:
+        return self._map(k)[1 + worker, :self.layout.shard_numel(k)]
+
+    # -- lifecycle ---------------------------------------------------------------------
+    def initialized(self) -> bool:
+        try:
+            self._c(0).get(INIT_KEY, timeout=0.0)
+            return True
+        except TimeoutError:
+            return False
+
+    def wait_initialized(self, timeout: float) -> bool:
+        try:
+            self._c(0).get(INIT_KEY, timeout=timeout)
+            return True
+        except TimeoutError:
+            return False
+
+    def _request_allocation(self):
+        for k in range(self.n):
+            self._c(k).set(ALLOC_KEY, struct.pack("<qq", self.layout.shard_numel(k), 1 + self.n_workers))
+        for k in range(self.n):
+            self._map(k)
+
+    def initialize(self, seed: int, only=None):
+        """Chief: have every ps task allocate its shard, then run the initializers INTO the shards."""
+        self._request_allocation()
+        for k in range(self.n):
+            if self.layout.shard_numel(k):
+                self.layout.initialize(self._params(k), seed, shard=k, slab_offset=self.layout.shard_range[k][0])
+        torch.cuda.synchronize(self.device)
+        self._c(0).set(INIT_KEY, b"1")
+
+    def write_all(self, local: torch.Tensor):
+        self._request_allocation()
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b > a:
+                self._params(k).copy_(local[a:b])
+        torch.cuda.synchronize(self.device)
+        self._c(0).set(INIT_KEY, b"1")
+
+    # -- data plane --------------------------------------------------------------------------
+    def pull(self, local: torch.Tensor, locked: bool = False):
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b > a:
+                local[a:b].copy_(self._params(k), non_blocking=True)
+
+    def push_apply(self, grads: torch.Tensor, lr: float, use_locking: bool = False, bump_step: bool = True):
+        lr_t = self._lr(lr)
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b <= a:
+                continue
+            p = self._params(k)
+            gs = p[self._gs_off:self._gs_off + 1] if (bump_step and k == self._gs_shard) else None
+            if use_locking:
+                self._c(k).qpop(LOCK_Q, timeout=self.timeout)
+                try:
+                    hb.sgd_apply_(p, grads[a:b], lr_t, 1.0, False, gs)
+                    torch.cuda.current_stream(self.device).synchronize()
+                finally:
+                    self._c(k).qpush(LOCK_Q, b"1")
+            else:
+                hb.sgd_apply_(p, grads[a:b], lr_t, 1.0, False, gs)
+
+    # -- SyncReplicas protocol ------------------------------------------------------------------
+    def push_accumulate(self, grads: torch.Tensor) -> bool:
+        ctl = self._c(self._gs_shard)
+        if self.local_step < ctl.add(ACC_STEP, 0):
+            self.dropped += 1                      # stale: the aggregate for that step is already applied
+            return False
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b > a:
+                self._mailbox(k, self.widx).copy_(grads[a:b], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is counted
+        ctl.add(ARRIVALS, 1)
+        return True
+
+    def dequeue_token(self) -> int:
+        try:
+            tok = self._c(self._gs_shard).qpop(TOKEN_Q, timeout=self.timeout)
+        except TimeoutError:
+            raise TimeoutError(
+                f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
+                f"is gone (replicas_to_aggregate == total_num_replicas leaves no spare)") from None
+        self.local_step = struct.unpack("<q", tok)[0]
+        return self.local_step
+
+    def aggregator_clients(self):
+        return [self.server.new_client("ps", k) for k in range(self.n)]
+
+    def take_apply_all(self, clients, num_required: int, lr: float, timeout: float) -> int:
+        """Chief aggregator: wait for N arrivals, then p -= lr/N * sum(mailboxes) on every shard."""
+        if num_required != self.n_workers:
+            raise NotImplementedError("ipc transport aggregates exactly one gradient per worker "
+                                      "(replicas_to_aggregate must equal the number of workers)")
+        ctl = clients[self._gs_shard]
+        ctl.wait_ge(ARRIVALS, num_required * (self._agg_round + 1), timeout=timeout)
+        stream = getattr(self, "_agg_stream", None)
+        if stream is None:
+            stream = self._agg_stream = torch.cuda.Stream(device=self.device)
+            self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(stream):
+            self._agg_lr.fill_(float(lr))
+            for k in range(self.n):
+                if not self.layout.shard_numel(k):
+                    continue
+                p = self._params(k)
+                for w in range(self.n_workers):
+                    last = w == self.n_workers - 1
+                    gs = p[self._gs_off:self._gs_off + 1] if (last and k == self._gs_shard) else None
+                    hb.sgd_apply_(p, self._mailbox(k, w), self._agg_lr, 1.0 / num_required, False, gs)
+        stream.synchronize()
+        self._agg_round += 1
+        ctl.add(ACC_STEP, 1)
+        return self.global_step()
+
+    def enqueue_tokens(self, clients, step: int, n: int):
+        clients[self._gs_shard].qpush(TOKEN_Q, struct.pack("<q", int(step)), copies=n)
+
+    def global_step(self) -> int:
+        torch.cuda.current_stream(self.device).synchronize()
+        return int(round(float(self._params(self._gs_shard)[self._gs_off].item())))
+
+    def close(self):
+        pass

@@ -1,0 +1,38 @@
+"""Collective (torch.distributed) replica trainers with gloo, world_size 2, on CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from cluster_utils import ROOT, free_ports
+
+
+def _run(mode, world=2, device="cpu", graph="eager"):
+    port = free_ports(1)[0]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), mode, device, graph]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.slow
+def test_sync_shards_and_towers_agree_and_replicas_stay_identical():
+    sync = _run("sync")
+    towers = _run("towers")
+    assert sync["replicas_identical"] and towers["replicas_identical"]
+    assert sync["global_step"] == 13 and towers["global_step"] == 13        # one update per N pushes
+    # reduce-scatter + sharded apply + all-gather == all-reduce + replicated apply (mean gradient)
+    assert abs(sync["checksum"] - towers["checksum"]) < 1e-3 * max(1.0, abs(sync["checksum"]))
+    assert abs(sync["loss"] - towers["loss"]) < 1e-4
+
+
+@pytest.mark.slow
+def test_async_rule_counts_every_worker_gradient():
+    res = _run("async")
+    assert res["replicas_identical"] and res["global_step"] == 26           # N updates per round

@@ -1,0 +1,106 @@
+"""GPU: the TF-style Session takes the fused HIP path; replica trainers capture hipGraphs; RCCL world of one."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import distributed_tensorflow_amd as tf
+from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+from distributed_tensorflow_amd.ops import reference as ref
+
+from cluster_utils import ROOT, cluster_dict, free_ports
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed, n=100):
+    rng = np.random.RandomState(seed)
+    return rng.rand(n, 784).astype(np.float32), np.eye(10, dtype=np.float32)[rng.randint(0, 10, n)]
+
+
+def test_local_session_runs_fused_kernels_and_matches_reference():
+    x, y = _batch(0)
+    with tf.Graph().as_default():
+        with tf.device("/gpu:0"):
+            m = build_model(0.1)
+        with tf.Session(config=tf.ConfigProto(allow_soft_placement=True)) as sess:
+            assert sess.device.type == "cuda"
+            sess.run(m.init_op)
+            p = {k: sess.var_tensor(getattr(m, k)).double().cpu() for k in ("W1", "b1", "W2", "b2")}
+            for _ in range(3):
+                _, cost, summ, step = sess.run([m.train_op, m.cross_entropy, m.summary_op, m.global_step],
+                                               {m.x: x, m.y_: y})
+            assert sess.fused_steps == 3 and sess.generic_steps == 0 and step == 2.0
+            for _ in range(3):
+                out = ref.mlp_grads(torch.tensor(x).double(), torch.tensor(y).double(), p["W1"], p["b1"], p["W2"], p["b2"])
+                for k in p:
+                    p[k] = p[k] - 0.1 * out["d" + k]
+            for k in p:
+                torch.testing.assert_close(sess.var_tensor(getattr(m, k)).cpu(), p[k].float(), rtol=2e-4, atol=2e-5)
+            assert abs(cost - float(out["loss"])) < 1e-3 and dict(summ.values)["cost"] == pytest.approx(cost)
+            tx, ty = _batch(9, 10000)
+            acc = sess.run(m.accuracy, {m.x: tx, m.y_: ty})
+            la = ref.mlp_loss_acc(torch.tensor(tx).double(), torch.tensor(ty).double(), p["W1"], p["b1"], p["W2"], p["b2"])
+            assert abs(acc - float(la[1])) < 2e-3
+
+
+def test_ps_session_on_gpu_worker_with_host_shards():
+    cluster = tf.train.ClusterSpec(cluster_dict(2, 1))
+    cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=20000)
+    servers = [tf.train.Server(cluster, "ps", i, config=cfg) for i in range(2)]
+    w = tf.train.Server(cluster, "worker", 0, config=cfg)
+    try:
+        with tf.Graph().as_default() as g:
+            with tf.device(tf.train.replica_device_setter(worker_device="/job:worker/task:0/gpu:0", cluster=cluster)):
+                m = build_model(0.05)
+            sv = tf.train.Supervisor(graph=g, is_chief=True, global_step=m.global_step, init_op=m.init_op)
+            with sv.prepare_or_wait_for_session(w.target) as sess:
+                assert sess.device.type == "cuda"
+                x, y = _batch(1)
+                c0 = sess.run(m.cross_entropy, {m.x: x, m.y_: y})
+                for _ in range(20):
+                    _, c, step = sess.run([m.train_op, m.cross_entropy, m.global_step], {m.x: x, m.y_: y})
+                assert c < c0 and step == 19.0 and sess.store.global_step() == 20 and sess.fused_steps == 20
+            sv.stop()
+    finally:
+        for s in servers + [w]:
+            s.stop()
+
+
+@pytest.mark.parametrize("mode", ["sync", "towers", "async"])
+def test_rccl_world_of_one_with_graph_capture(mode):
+    """The collective step (kernels + RCCL calls + sharded SGD) captured into hipGraphs; world size 1."""
+    port = free_ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py"), mode, "cuda", "graph"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["global_step"] == 13 and "hipGraph" in res["desc"] and res["loss"] == res["loss"]
+
+
+@pytest.mark.parametrize("script,n_ps,n_w", [("tfdist_between.py", 1, 1), ("tfdist_between.py", 2, 2),
+                                             ("tfdist_between_sync.py", 1, 2)])
+def test_ipc_transport_gpu_resident_shards(script, n_ps, n_w, tmp_path):
+    """PS and workers as separate processes sharing the GPU; shards live in the PS task's HBM (HIP-IPC)."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=1", "--train_size=1100", "--freq=5", "--lr=0.01", "--nosummaries", "--transport=ipc",
+            f"--logs_path={tmp_path}"]
+    res = launch_script(script, n_ps, n_w, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    assert "resident on cuda" in res["ps0"][1]
+    finals = []
+    for i in range(n_w):
+        out = res[f"worker{i}"][1]
+        assert out.rstrip().endswith("Done")
+        steps = [int(s) for s in re.findall(r"Step: (\d+),", out)]
+        finals.append(steps[-1])
+    assert finals == [11] * n_w if "sync" in script else max(finals) == 11 * n_w
