@@ -63,7 +63,22 @@ def run_benchmark(args) -> Optional[dict]:
                                     use_graph=not args.no_graph)
     steps, warmup = int(args.steps), int(args.warmup)
 
-    trainer.prepare(steps_hint=(warmup, steps))
+    # Capture the hipGraph chunks outside the timed region.  If capture fails on any rank
+    # (e.g. an RCCL build that cannot be captured) every rank falls back to eager launches.
+    ok = 1
+    try:
+        trainer.prepare(steps_hint=(warmup, steps, STEPS_PER_EPOCH))
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); using eager launches", flush=True)
+    if distributed:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok and trainer.use_graph:
+        trainer.use_graph = False
+        trainer._graphs.clear()
+        trainer.engine.reset_step_workspace(trainer.engine.parity)
     trainer.run_steps(warmup)
     _sync(device, distributed)
     t0 = time.perf_counter()

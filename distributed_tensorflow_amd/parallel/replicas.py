@@ -186,8 +186,8 @@ class SingleTrainer(_BaseTrainer):
         self.engine.step_fused(batch_index)
 
     def describe(self):
-        return "single (no PS): 3 fused kernels/step, hipGraph chunks of %d" % self.chunk if self.use_graph \
-            else "single (no PS): 3 fused kernels/step, eager"
+        return "single (no PS): 2 fused launches/step, hipGraph chunks of %d" % self.chunk if self.use_graph \
+            else "single (no PS): 2 fused launches/step, eager"
 
 
 class _CollectiveTrainer(_BaseTrainer):

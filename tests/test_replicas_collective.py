@@ -36,3 +36,30 @@ def test_sync_shards_and_towers_agree_and_replicas_stay_identical():
 def test_async_rule_counts_every_worker_gradient():
     res = _run("async")
     assert res["replicas_identical"] and res["global_step"] == 26           # N updates per round
+
+
+def test_in_graph_towers_mean_gradient_and_identical_replicas():
+    import numpy as np
+    import torch
+
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.parallel.towers import InGraphTowers
+
+    rng = np.random.RandomState(0)
+    images = rng.rand(400, 784).astype(np.float32)
+    labels = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 400)]
+    tw = InGraphTowers(["cpu", "cpu"], images, labels, batch=100, lr=0.05, seed=1)
+    p = {k: v.clone() for k, v in tw.layout.mlp_views(tw.params[0]).items()}
+    batches = [(ds.x_epoch[:100].clone(), ds.y_epoch[:100].clone()) for ds in tw.datasets]
+    tw.step()
+    assert tw.replicas_identical() and tw.global_step_value() == 1
+    g = {k: torch.zeros_like(v) for k, v in p.items()}
+    for xb, yb in batches:
+        out = ref.mlp_grads(xb, yb, p["W1"], p["b1"], p["W2"], p["b2"])
+        for k in g:
+            g[k] += out["d" + k] / 2
+    got = tw.layout.mlp_views(tw.params[1])
+    for k in p:
+        torch.testing.assert_close(got[k], p[k] - 0.05 * g[k], rtol=1e-5, atol=1e-6)
+    tw.run_steps(5)                       # crosses the 4-batch epoch boundary (reshuffle)
+    assert tw.replicas_identical() and tw.global_step_value() == 6
