@@ -101,27 +101,65 @@ def main():
     print("  %-24s %7d ns %8d cyc" % ("total", (s[7, 0] - s[0, 0]) * 10, s[7, 1] - s[0, 1]))
 
 
-def bwd_stamps():
+def bwd_stamps(block=1, label="main block 1"):
     eng = make_engine()
     lib = hb.require()
+    lib.dtf_debug_set_bwd_stamp_block.argtypes = [C.c_int]
+    lib.dtf_debug_set_bwd_stamp_block.restype = None
+    lib.dtf_debug_set_bwd_stamp_block(block)
     d = eng._descriptor()
     stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
     lib.dtf_debug_set_bwd_stamps.argtypes = [C.c_void_p]
     lib.dtf_debug_set_bwd_stamps.restype = None
     lib.dtf_debug_set_bwd_stamps(stamps.data_ptr())
-    for _ in range(3):
-        hb.mlp_step_fused(d, 0, 0)
+    for i in range(4):
+        hb.mlp_step_fused(d, 0, i & 1)
     torch.cuda.synchronize()
     lib.dtf_debug_set_bwd_stamps(None)
     s = stamps.cpu().view(16, 2)
     names = ["start", "loads issued", "staged+sync", "logits/softmax+sync", "dW1 mfma loop", "red write+sync",
              "epilogue", "duties"]
-    print("bwd_all phases (last block, thread 0): wall ns / shader cycles")
+    print("bwd_all phases (%s, thread 0): wall ns / shader cycles" % label)
     for i in range(1, 8):
         print("  %-24s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
     print("  %-24s %7d ns %8d cyc" % ("total", (s[7, 0] - s[0, 0]) * 10, s[7, 1] - s[0, 1]))
 
 
+def block_stamps():
+    eng = make_engine()
+    lib = hb.require()
+    d = eng._descriptor()
+    n = 2 * (64 + 128)
+    stamps = torch.zeros(n, dtype=torch.int64, device="cuda")
+    lib.dtf_debug_set_block_stamps.argtypes = [C.c_void_p]
+    lib.dtf_debug_set_block_stamps.restype = None
+    g = torch.cuda.CUDAGraph()
+    for q in (0, 1):
+        hb.mlp_step_fused(d, 0, q)
+    torch.cuda.synchronize()
+    lib.dtf_debug_set_block_stamps(stamps.data_ptr())
+    with torch.cuda.graph(g):
+        for i in range(6):
+            hb.mlp_step_fused(d, 0, i & 1)
+    lib.dtf_debug_set_block_stamps(None)
+    g.replay()
+    torch.cuda.synchronize()
+    s = stamps.cpu().view(-1, 2)
+    f, b = s[:49], s[64:64 + 108]
+    t0 = int(f[:, 0].min())
+    rel = lambda x: (int(x) - t0) * 10   # noqa: E731
+    print("grid timing of the LAST captured step (ns, relative to the first forward block start):")
+    print("  fwd  blocks start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
+    print("  bwd  blocks start %5d..%5d   end %5d..%5d" % (rel(b[:, 0].min()), rel(b[:, 0].max()), rel(b[:, 1].min()), rel(b[:, 1].max())))
+    dur = (b[:, 1] - b[:, 0]) * 10
+    print("  bwd  block durations: min %d median %d max %d; duty blocks (last 8): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-8:]]))
+    durf = (f[:, 1] - f[:, 0]) * 10
+    print("  fwd  block durations: min %d median %d max %d" % (int(durf.min()), int(durf.median()), int(durf.max())))
+
+
 if __name__ == "__main__":
-    bwd_stamps()
+    block_stamps()
+    bwd_stamps(1, "main block 1")
+    bwd_stamps(-1, "stats block: 3=softmax done,4=db2,5=hist stores,6=global_step rmw")
+    sys.exit(0)
     main()

@@ -44,6 +44,26 @@ __device__ __forceinline__ float fast_act(float z, int act) {
   return fmaxf(z, 0.0f);
 }
 
+// Guarded loads WITHOUT control flow: the load always executes (from element 0 when the guard
+// fails) and the value is selected afterwards.  Writing `ok ? p[i] : 0.f` makes hipcc branch
+// around the load and wait for vmcnt(0) per element, which serialises what should be one batch
+// of loads in flight.
+// ld_c / ld4_c return the RAW value (element 0 when the guard fails): the caller masks it at the
+// point of use, AFTER every load of the kernel has been issued.  Masking right at the load makes
+// the compiler wait for each load group before it issues the next one (one memory round trip per
+// group instead of one per kernel).
+__device__ __forceinline__ float ld_c(const float* __restrict__ p, int idx, bool ok) { return p[ok ? idx : 0]; }
+// Cheapest form: a 32-bit unsigned element offset already clamped into the buffer by the caller
+// (one v_min_u32); compiles to `global_load_dword v, voff, s[base]` with no 64-bit arithmetic.
+__device__ __forceinline__ float ld_u(const float* __restrict__ p, unsigned off) { return p[off]; }
+__device__ __forceinline__ f32x4 ld4_u(const float* __restrict__ p, unsigned off) {
+  return *reinterpret_cast<const f32x4*>(p + off);
+}
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ f32x4 ld4_c(const float* __restrict__ p, int idx, bool ok) {
+  return *reinterpret_cast<const f32x4*>(p + (ok ? idx : 0));
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(
@@ -95,6 +115,15 @@ __device__ __forceinline__ int row16_argmax(float v, int idx) {  // ties -> smal
 //   z3[m][c] += sum_{h in tile} a2[m][h] W2[h][c],
 // into the ping-pong accumulator zacc (7 workgroups per row tile, f32 atomics),
 // and block 0 zeroes the OTHER ping-pong half for the next step.
+// Optional per-block {start, end} wall-clock stamps (100 MHz) for grid-level timing studies.
+struct BlockStamps {
+  long long* buf;   // [2 * blocks] or null
+};
+#define DTF_BLOCK_STAMP(bs, which)                                                        \
+  do {                                                                                    \
+    if ((bs).buf && threadIdx.x == 0) (bs).buf[2 * blockIdx.x + (which)] = (long long)wall_clock64(); \
+  } while (0)
+
 constexpr int kFwdWaves = 16;
 constexpr int kFwdMaxMs = 4;  // macro-steps per wave held in registers (K <= 1024)
 
@@ -102,7 +131,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
     const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
     const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
     float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
-    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2) {
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
+  DTF_BLOCK_STAMP(bs, 0);
   __shared__ float red[kFwdWaves][4][64];
   __shared__ float a2t[16][17];
   __shared__ float w2t[16][17];
@@ -120,9 +150,10 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   // epilogue operands, requested up front (threads < 256 own one tile element each)
   const int e_reg = threadIdx.x >> 6, e_lane = threadIdx.x & 63;
   const int e_col = n0 + (e_lane & 15);
-  const float bias = (threadIdx.x < 256 && e_col < H) ? b[e_col] : 0.f;
-  const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;   // threads < 256: W2 tile element
-  const float w2v = (threadIdx.x < 256 && n0 + w_h < H && w_c < C) ? W2[(n0 + w_h) * C + w_c] : 0.f;
+  const float bias = ld_c(b, e_col, e_col < H);              // used by threads < 256 only, store guarded
+  const int w_h = (threadIdx.x >> 4) & 15, w_c = threadIdx.x & 15;   // threads < 256: W2 tile element
+  const bool w2_ok = n0 + w_h < H && w_c < C;
+  const float w2raw = ld_c(W2, (n0 + w_h) * C + w_c, w2_ok);
 
   // block 0: refresh the shadow copy of W2/b2 and clear the other logit accumulator
   if (blockIdx.x == 0) {
@@ -133,6 +164,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
     for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
   }
 
+  const unsigned row_c = row_ok ? row : M - 1, col_c = col_ok ? col : H - 1;
+  const unsigned a_max = (unsigned)M * K - 4, b_max = (unsigned)K * H - 1;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int base = wave; base < nms; base += kFwdWaves * kFwdMaxMs) {
     f32x4 a[kFwdMaxMs], bv[kFwdMaxMs];
@@ -140,29 +173,24 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
     for (int j = 0; j < kFwdMaxMs; ++j) {
       const int ms = base + j * kFwdWaves;
       const int kb = ms * 16 + q * 4;
-      a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ms < nms) {
-        if (row_ok) {
-          const float* px = X + (long)row * K + kb;
-          if (vec_ok && kb + 3 < K) {
-            a[j] = *reinterpret_cast<const f32x4*>(px);
-          } else {
+      // Offsets are clamped into the operands (one v_min each), values stay raw; B gets its K
+      // mask just before the MFMA so that out-of-range k contribute a * 0, and rows beyond M
+      // only feed output rows that are never stored.
+      if (vec_ok) {   // K % 4 == 0: a macro-step quarter is either fully inside K or fully outside
+        a[j] = ld4_u(X, umin_(row_c * K + kb, a_max));
+      } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-              if (kb + s < K) a[j][s] = px[s];
-          }
-        }
-        if (col_ok) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            if (kb + s < K) bv[j][s] = W[(long)(kb + s) * H + col];
-        }
+        for (int s = 0; s < 4; ++s) a[j][s] = ld_u(X, umin_(row_c * K + kb + s, a_max + 3));
       }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[j][s] = ld_u(W, umin_((kb + s) * H + col_c, b_max));
     }
 #pragma unroll
     for (int j = 0; j < kFwdMaxMs; ++j) {
       if (base + j * kFwdWaves < nms) {  // wave-uniform
+        const int kb = (base + j * kFwdWaves) * 16 + q * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bv[j][s] = (col_ok && kb + s < K) ? bv[j][s] : 0.f;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], bv[j][0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], bv[j][1], acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], bv[j][2], acc0, 0, 0, 0);
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   const f32x4 acc = acc0 + acc1;
 #pragma unroll
   for (int g = 0; g < 4; ++g) red[wave][g][lane] = acc[g];
-  if (threadIdx.x < 256) w2t[w_h][w_c] = w2v;
+  if (threadIdx.x < 256) w2t[w_h][w_c] = w2_ok ? w2raw : 0.f;
   __syncthreads();
   if (threadIdx.x < 256) {
     float s = 0.f;
@@ -198,6 +226,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
       atomicAdd(&zacc[(m0 + lrow) * 16 + c], z);
     }
   }
+  DTF_BLOCK_STAMP(bs, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -227,261 +256,323 @@ struct BwdParams {
   float* global_step;
   int M, K, H, C, R, act, fused;
   long long* stamps;      // optional phase stamps (profiling)
+  int stamp_block;        // which block records them (negative: counted from the end of the grid)
+  BlockStamps bs;
 };
 
 #define DTF_STAMP2(i)                                                          \
   do {                                                                         \
-    if (p.stamps && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {         \
+    if (p.stamps && threadIdx.x == 0 && (int)blockIdx.x == p.stamp_block) {    \
       p.stamps[2 * (i)] = (long long)wall_clock64();                           \
       p.stamps[2 * (i) + 1] = (long long)clock64();                            \
     }                                                                          \
   } while (0)
 
+// Grid = [main blocks: one 32x32 tile of dW1 each] ++ [duty blocks: one 16-row tile of dW2
+// each, then one block for db2 + step statistics].  Duty blocks run beside the main blocks
+// instead of lengthening some of them.  Every block first rebuilds dz3 for the whole batch
+// from the 6 KB logit accumulator: one THREAD per batch row walks its 10 classes in
+// registers (no cross-lane traffic, ~100 instructions), which is shorter than a
+// lane-parallel softmax with 16-lane reductions.
+constexpr int kLdz = 20;   // dz3s row stride: 16-B aligned rows (broadcast b128 reads), 4-way banks on writes
+
 __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
-  __shared__ __attribute__((aligned(16))) float dz3s[128 * 16];   // [R][16]
-  __shared__ float red[kBwdWaves * 16 * 64];                      // partial tiles / scratch
-  __shared__ float w2t[32 * kLdw];                                // W2 rows of this h tile
-  __shared__ float a2d[128 * kLdw];                               // dW2 duty: a2 column tile
-  __shared__ float b2s[16];
-  __shared__ float scal[4];
+  __shared__ __attribute__((aligned(16))) float smem[8192 + 128 * kLdz + 32 * kLdw + 128 * kLdw + 64];
+  float* red = smem;                         // [8][16][64] partial tiles (phase 2+)
+  float* zs = smem;                          // [R][17] logits      (phase 1, aliases red)
+  float* ys = smem + 128 * kLdw;             // [R][17] labels      (phase 1, aliases red)
+  float* dz3s = smem + 8192;                 // [R][kLdz]
+  float* w2t = dz3s + 128 * kLdz;            // [32][17] W2 rows of this h tile
+  float* a2d = w2t + 32 * kLdw;              // [R][17] dW2 duty: a2 column tile
+  float* b2s = a2d + 128 * kLdw;             // [16]
+  float* db2s = b2s + 16;                    // [16]
+  float* scal = db2s + 16;                   // [0] loss sum, [1] correct count
 
   const int R = p.R, H = p.H, C = p.C, M = p.M, K = p.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, q = lane >> 4;
   const int r32 = lane & 31, half = lane >> 5;
   const int tiles_h = (H + 31) >> 5;
-  const int th = blockIdx.x % tiles_h, tk = blockIdx.x / tiles_h;
-  const int k0 = tk * 32, h0 = th * 32;
+  const int n_main = tiles_h * ((K + 31) >> 5);
   const int h_tiles = (H + 15) >> 4;
-  const int n_duties = h_tiles + 1;
-  const bool stats_block = blockIdx.x == (unsigned)(h_tiles % gridDim.x);
+  const bool is_main = (int)blockIdx.x < n_main;
+  const int duty = is_main ? -1 : (int)blockIdx.x - n_main;     // 0..h_tiles-1: dW2 tile; h_tiles: db2+stats
+  const bool stats_block = duty == h_tiles;
+  const int th = is_main ? (int)blockIdx.x % tiles_h : 0, tk = is_main ? (int)blockIdx.x / tiles_h : 0;
+  const int k0 = tk * 32, h0 = th * 32;
 
+  DTF_BLOCK_STAMP(p.bs, 0);
   DTF_STAMP2(0);
   // ---- phase 0: issue every global load -------------------------------------
   const float* __restrict__ X = p.xbase + p.batch_index * (long)M * (long)K;
   const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;
-  const float lr = p.fused ? *p.lr : 0.f;
+  const float lr = *p.lr;   // always a valid pointer (checked by the launcher): no branch before the loads
 
-  // logits + labels, flat [row][16] image: thread element e = tid + u*512
+  // Every index below is a 32-bit offset clamped into its buffer with one v_min; values are
+  // masked where they are consumed (or need no mask at all), so the whole batch of loads is in
+  // flight before the first wait.
+  // logits + labels, flat [row][16] image: thread element e = tid + u*512 (the accumulator holds
+  // 2048 floats, rows >= M are zero: no clamp needed)
   float zreg[4], yreg[4];
+  const unsigned y_max = (unsigned)M * C - 1;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * kBwdThreads;
-    const int row = e >> 4, c = e & 15;
-    const bool ok = row < M && c < C;
-    zreg[u] = ok ? p.zacc[e] : 0.f;
-    yreg[u] = ok ? Y[(long)row * C + c] : 0.f;
+    const unsigned e = tid + u * kBwdThreads;
+    zreg[u] = ld_u(p.zacc, e);
+    yreg[u] = ld_u(Y, umin_((e >> 4) * C + (e & 15), y_max));      // masked when staged into LDS
   }
-  const float b2reg = tid < C ? p.b2r[tid] : 0.f;
-  // W2 rows of this h tile
-  const int wt_h = tid >> 4, wt_c = tid & 15;     // 512 threads = 32 rows x 16
-  const float w2reg = (h0 + wt_h < H && wt_c < C) ? p.W2r[(h0 + wt_h) * C + wt_c] : 0.f;
-  // dW1 operands in MFMA layout: wave w owns batch-row pairs w, w+8, ...
+  const float b2raw = ld_u(p.b2r, umin_(tid, C - 1));
   const int nsteps = (M + 1) >> 1;
   const int kk = k0 + r32, hh = h0 + r32;
   float xreg[kMaxSteps], areg[kMaxSteps];
-#pragma unroll
-  for (int j = 0; j < kMaxSteps; ++j) {
-    const int m = 2 * (wave + j * kBwdWaves) + half;
-    xreg[j] = (m < M && kk < K) ? X[(long)m * K + kk] : 0.f;
-    areg[j] = (m < M && hh < H) ? p.a2[(long)m * H + hh] : 0.f;
-  }
-  // old W1 values of this thread's two output elements (fused update)
   float wold[2] = {0.f, 0.f};
-  if (p.fused) {
+  float w2reg = 0.f, b1old = 0.f, w2old = 0.f;
+  float dreg[4] = {0.f, 0.f, 0.f, 0.f};
+  if (is_main) {
+    // W2 rows of this h tile; dW1 operands in MFMA layout (wave w owns batch-row pairs w, w+8, ...)
+    w2reg = ld_u(p.W2r, umin_((h0 + (tid >> 4)) * C + (tid & 15), (unsigned)H * C - 1));   // masked when staged
+    // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
+    // dz2 is 0 there whatever (finite) value was read; tile rows k >= K are never stored.
+    const unsigned kc = umin_(kk, K - 1), hc = umin_(hh, H - 1);
+    const unsigned x_max = (unsigned)(M - 1) * K + kc, a_max = (unsigned)(M - 1) * H + hc;
+    unsigned xo = (2 * wave + half) * K + kc, ao = (2 * wave + half) * H + hc;
+#pragma unroll
+    for (int j = 0; j < kMaxSteps; ++j) {
+      xreg[j] = ld_u(X, umin_(xo, x_max));
+      areg[j] = ld_u(p.a2, umin_(ao, a_max));
+      xo += 2 * kBwdWaves * K;
+      ao += 2 * kBwdWaves * H;
+    }
+    // fused mode reads the old weights; in gradient mode the same (valid) locations of the
+    // gradient slab are read and ignored, which keeps the loads free of control flow
+    const unsigned w_max = (unsigned)K * H - 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = tid + j * kBwdThreads;
       const int g = e >> 6, l = e & 63;
-      const int orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-      const int ocol = h0 + (l & 31);
-      wold[j] = (orow < K && ocol < H) ? p.oW1[(long)orow * H + ocol] : 0.f;
+      const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+      const unsigned ocol = h0 + (l & 31);
+      wold[j] = ld_u(p.oW1, umin_(orow * H + ocol, w_max));
     }
-  }
-  const float b1old = (p.fused && tk == 0 && tid < 32 && h0 + tid < H) ? p.ob1[h0 + tid] : 0.f;
-  // dW2 duty: a2 column tile [R][16] (first duty of this block, if any)
-  const int duty0 = blockIdx.x < (unsigned)h_tiles ? (int)blockIdx.x : -1;
-  float dreg[4] = {0.f, 0.f, 0.f, 0.f};
-  float w2old = 0.f;   // old value of this thread's dW2 duty element (threads < 256)
-  if (duty0 >= 0 && tid < 256) {
-    const int h = duty0 * 16 + 4 * ((tid & 63) >> 4) + (tid >> 6), c = tid & 15;
-    w2old = (h < H && c < C) ? p.W2r[h * C + c] : 0.f;
-  }
-  if (duty0 >= 0) {
+    b1old = ld_u(p.ob1, umin_(h0 + (tid & 31), H - 1));
+  } else if (!stats_block) {
+    // dW2 duty: a2 column tile [R][16] and the old W2 tile values
+    const unsigned a_max = (unsigned)M * H - 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * kBwdThreads;
-      const int row = e >> 4, hcol = duty0 * 16 + (e & 15);
-      dreg[u] = (row < M && hcol < H) ? p.a2[(long)row * H + hcol] : 0.f;
+      const unsigned e = tid + u * kBwdThreads;
+      dreg[u] = ld_u(p.a2, umin_((e >> 4) * H + duty * 16 + (e & 15), a_max));   // masked when staged
+    }
+    {
+      const unsigned h = duty * 16 + 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3), c = tid & 15;
+      w2old = ld_u(p.W2r, umin_(h * C + c, (unsigned)H * C - 1));              // store is guarded
     }
   }
 
   DTF_STAMP2(1);
-  // ---- phase 1: softmax-xent on the flat image (one 16-lane DPP row per batch row) ---
-  if (tid < 16) b2s[tid] = b2reg;
+  // ---- phase 1: stage logits/labels, then softmax-xent with one thread per batch row ----------
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * kBwdThreads;
+    if (e < R * 16) {
+      const bool ok = (e >> 4) < M && (e & 15) < C;
+      zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
+      ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
+    }
+  }
+  if (tid < 16) {
+    b2s[tid] = tid < C ? b2raw : 0.f;
+    db2s[tid] = 0.f;
+  }
   if (tid < 4) scal[tid] = 0.f;
-  w2t[wt_h * kLdw + wt_c] = w2reg;
-  if (duty0 >= 0) {
+  if (is_main) {
+    w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + (tid >> 4) < H && (tid & 15) < C) ? w2reg : 0.f;
+  } else if (!stats_block) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + u * kBwdThreads;
-      if (e < R * 16) a2d[(e >> 4) * kLdw + (e & 15)] = dreg[u];
+      if (e < R * 16) a2d[(e >> 4) * kLdw + (e & 15)] = ((e >> 4) < M && duty * 16 + (e & 15) < H) ? dreg[u] : 0.f;
     }
   }
   __syncthreads();
   const float inv_batch = 1.0f / (float)M;
   {
-    const bool col_ok = i16 < C;
-    const float bias2 = b2s[i16];
-    float wloss = 0.f, wcorrect = 0.f;
+    // four threads per batch row, four classes each; row reductions are two quad-DPP steps
+    const int row = tid >> 2, part = tid & 3;
+    const bool row_ok = row < M;
+    float z[4], y[4], ex[4];
+    float mx = -INFINITY, ysum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * kBwdThreads;
-      const int row = e >> 4;
-      const bool row_ok = row < M;
-      const float z = zreg[u] + bias2;
-      const float zm = col_ok ? z : -INFINITY;
-      const float mx = row16_max(zm);
-      const float ex = col_ok ? fast_exp(z - mx) : 0.f;
-      const float se = row16_sum(ex);
-      const float prob = ex * fast_rcp(se);
-      const float y = yreg[u];
-      const float ysum = row16_sum(y);
-      if (e < R * 16) dz3s[e] = (row_ok && col_ok) ? (prob * ysum - y) * inv_batch : 0.f;
-      if (stats_block) {   // block-uniform
-        const float logp = z - mx - fast_log(se);
-        const float rloss = row16_sum(col_ok ? -y * logp : 0.f);
-        const int az = row16_argmax(zm, i16);
-        const int ay = row16_argmax(col_ok ? y : -INFINITY, i16);
-        if (row_ok && i16 == 0) {
-          wloss += rloss;
-          wcorrect += (az == ay) ? 1.f : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * part + i;
+      z[i] = zs[row * kLdw + c] + b2s[c];
+      y[i] = ys[row * kLdw + c];
+      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
+      ysum += y[i];                                   // zero beyond C
+    }
+    mx = fmaxf(mx, dpp_f<kXor1>(mx));
+    mx = fmaxf(mx, dpp_f<kXor2>(mx));
+    ysum += dpp_f<kXor1>(ysum);
+    ysum += dpp_f<kXor2>(ysum);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
+      se += ex[i];
+    }
+    se += dpp_f<kXor1>(se);
+    se += dpp_f<kXor2>(se);
+    const float inv = fast_rcp(se) * ysum;
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
+    if (row < R) *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
+    if (stats_block) {   // block-uniform
+      const float lse = mx + fast_log(se);
+      float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
+      int az = 0, ay = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * part + i;
+        if (c < C) {
+          rloss -= y[i] * (z[i] - lse);
+          if (z[i] > bz) { bz = z[i]; az = c; }     // strict > keeps the smallest index on ties
+          if (y[i] > by) { by = y[i]; ay = c; }
         }
       }
-    }
-    if (stats_block) {
-      wloss += __shfl_xor(wloss, 16);
-      wloss += __shfl_xor(wloss, 32);
-      wcorrect += __shfl_xor(wcorrect, 16);
-      wcorrect += __shfl_xor(wcorrect, 32);
-      if (lane == 0) {
-        atomicAdd(&scal[0], wloss);
-        atomicAdd(&scal[1], wcorrect);
+      rloss += dpp_f<kXor1>(rloss);
+      rloss += dpp_f<kXor2>(rloss);
+      argmax_step<kXor1>(bz, az);
+      argmax_step<kXor2>(bz, az);
+      argmax_step<kXor1>(by, ay);
+      argmax_step<kXor2>(by, ay);
+      if (part == 0 && row < 128) {
+        a2d[row] = row_ok ? rloss : 0.f;             // a2d is free in the statistics block
+        a2d[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
       }
     }
   }
   __syncthreads();
   DTF_STAMP2(2);
-
-  // ---- phase 2: dW1 tile; dz2 is formed in registers as the MFMA B operand --------------
-  float w2row[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) w2row[c] = w2t[r32 * kLdw + c];
-  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float db1part = 0.f;
-#pragma unroll
-  for (int j = 0; j < kMaxSteps; ++j) {
-    const int step = wave + j * kBwdWaves;
-    if (step < nsteps) {   // wave-uniform
-      const int m = 2 * step + half;          // < R (R = M rounded up to 16)
-      const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + m * 16);   // broadcast reads
-      const f32x4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
-      float da = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        da += d0[c] * w2row[c];
-        da += d1[c] * w2row[4 + c];
-        da += d2[c] * w2row[8 + c];
-        da += d3[c] * w2row[12 + c];
-      }
-      const float dz2 = da * dtf_act_bwd(areg[j], p.act);   // areg is 0 outside the valid range
-      db1part += dz2;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[j], dz2, acc, 0, 0, 0);
-    }
-  }
-  DTF_STAMP2(3);
-#pragma unroll
-  for (int g = 0; g < 16; ++g) red[(wave * 16 + g) * 64 + lane] = acc[g];
-  __syncthreads();
-  DTF_STAMP2(4);
   const float gs = p.grad_scale;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * kBwdThreads;
-    const int g = e >> 6, l = e & 63;
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 16 + g) * 64 + l];
-    const int orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-    const int ocol = h0 + (l & 31);
-    if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[j] - lr * s : gs * s;
-  }
-  DTF_STAMP2(5);
 
-  // ---- duty: db1 (workgroups of k-tile 0 see every batch row of their columns) -----
-  if (tk == 0) {
-    __syncthreads();   // red is reused
-    db1part += __shfl_xor(db1part, 32);
-    if (lane < 32) red[wave * 32 + lane] = db1part;
+  if (is_main) {
+    // ---- phase 2: dW1 tile; dz2 is formed in registers as the MFMA B operand --------------
+    float w2row[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w2row[c] = w2t[r32 * kLdw + c];
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float db1part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxSteps; ++j) {
+      const int step = wave + j * kBwdWaves;
+      if (step < nsteps) {   // wave-uniform
+        const int m = 2 * step + half;          // < R (R = M rounded up to 16)
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + m * kLdz);   // broadcast reads
+        const f32x4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
+        float da = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          da += d0[c] * w2row[c];
+          da += d1[c] * w2row[4 + c];
+          da += d2[c] * w2row[8 + c];
+          da += d3[c] * w2row[12 + c];
+        }
+        const float dz2 = da * dtf_act_bwd(areg[j], p.act);   // areg is 0 outside the valid range
+        db1part += dz2;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[j], dz2, acc, 0, 0, 0);
+      }
+    }
+    DTF_STAMP2(3);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) red[(wave * 16 + g) * 64 + lane] = acc[g];
     __syncthreads();
-    if (tid < 32 && h0 + tid < H) {
+    DTF_STAMP2(4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * kBwdThreads;
+      const int g = e >> 6, l = e & 63;
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBwdWaves; ++w) s += red[w * 32 + tid];
-      p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
+      for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 16 + g) * 64 + l];
+      const int orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+      const int ocol = h0 + (l & 31);
+      if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[j] - lr * s : gs * s;
     }
-  }
-  DTF_STAMP2(6);
-
-  // ---- duties dealt round-robin over the grid: dW2 tiles, then db2 + statistics -------
-  for (int duty = blockIdx.x; duty < n_duties; duty += gridDim.x) {
-    __syncthreads();   // red / a2d are reused
-    if (duty < h_tiles) {
-      if (duty != duty0) {   // grids smaller than the duty list: stage this tile now
-        for (int e = tid; e < R * 16; e += kBwdThreads) {
-          const int row = e >> 4, hcol = duty * 16 + (e & 15);
-          a2d[row * kLdw + (e & 15)] = (row < M && hcol < H) ? p.a2[(long)row * H + hcol] : 0.f;
-        }
-        __syncthreads();
-      }
-      // dW2[h][c] = sum_b a2[b][h] dz3[b][c] for h in tile `duty`; waves split the batch
-      const float* arow = a2d + q * kLdw + i16;
-      const float* brow = dz3s + q * 16 + i16;
-      f32x4 d = {0.f, 0.f, 0.f, 0.f};
-      for (int kb = wave * 4; kb < R; kb += kBwdWaves * 4)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * kLdw], brow[kb * 16], d, 0, 0, 0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) red[(wave * 4 + g) * 64 + lane] = d[g];
+    DTF_STAMP2(5);
+    // db1: the workgroups of k-tile 0 see every batch row of their 32 columns
+    if (tk == 0) {
+      __syncthreads();   // red is reused
+      db1part += __shfl_xor(db1part, 32);
+      if (lane < 32) red[wave * 32 + lane] = db1part;
       __syncthreads();
-      if (tid < 256) {
-        const int g = tid >> 6, l = tid & 63;
+      if (tid < 32 && h0 + tid < H) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + g) * 64 + l];
-        const int h = duty * 16 + 4 * (l >> 4) + g, c = l & 15;
-        if (h < H && c < C) {
-          // fused: old value from the read-side copy (never the live tensor other blocks may be writing)
-          const float old = (duty == duty0) ? w2old : p.W2r[h * C + c];
-          p.oW2[h * C + c] = p.fused ? old - lr * s : gs * s;
-        }
+        for (int w = 0; w < kBwdWaves; ++w) s += red[w * 32 + tid];
+        p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
       }
-    } else {
-      if (tid < C) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) s += dz3s[r * 16 + tid];
-        p.ob2[tid] = p.fused ? b2s[tid] - lr * s : gs * s;
+    }
+    DTF_STAMP2(6);
+  } else if (!stats_block) {
+    // ---- duty: dW2[h][c] = sum_b a2[b][h] dz3[b][c] for h in tile `duty`; waves split the batch
+    const float* arow = a2d + q * kLdw + i16;
+    const float* brow = dz3s + q * kLdz + i16;
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = wave * 4; kb < R; kb += kBwdWaves * 4)
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * kLdw], brow[kb * kLdz], d, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(wave * 4 + g) * 64 + lane] = d[g];
+    __syncthreads();
+    if (tid < 256) {
+      const int g = tid >> 6, l = tid & 63;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + g) * 64 + l];
+      const int h = duty * 16 + 4 * (l >> 4) + g, c = l & 15;
+      if (h < H && c < C) p.oW2[h * C + c] = p.fused ? w2old - lr * s : gs * s;
+    }
+  } else {
+    // ---- duty: db2 and the step statistics -------------------------------------------------
+    DTF_STAMP2(3);
+    {
+      const int c = tid & 15, part = tid >> 4;      // 32 row groups x 16 classes
+      float s = 0.f;
+      for (int r = part; r < R; r += kBwdThreads / 16) s += dz3s[r * kLdz + c];
+      atomicAdd(&db2s[c], s);
+    }
+    if (wave == 0) {   // sum the per-row loss / correct flags: 2 values per lane, then a wave reduction
+      float l = (lane < R ? a2d[lane] : 0.f) + (lane + 64 < R ? a2d[lane + 64] : 0.f);
+      float k = (lane < R ? a2d[128 + lane] : 0.f) + (lane + 64 < R ? a2d[128 + lane + 64] : 0.f);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        l += __shfl_xor(l, m);
+        k += __shfl_xor(k, m);
       }
-      if (tid == 0) {
-        if (p.loss_hist) p.loss_hist[p.hist_slot] = scal[0] * inv_batch;
-        if (p.acc_hist) p.acc_hist[p.hist_slot] = scal[1] * inv_batch;
-        if (p.fused && p.global_step) *p.global_step = *p.global_step + 1.0f;
+      if (lane == 0) {
+        scal[0] = l;
+        scal[1] = k;
       }
+    }
+    __syncthreads();
+    DTF_STAMP2(4);
+    if (tid < C) p.ob2[tid] = p.fused ? b2s[tid] - lr * db2s[tid] : gs * db2s[tid];
+    if (tid == 0) {
+      if (p.loss_hist) p.loss_hist[p.hist_slot] = scal[0] * inv_batch;
+      if (p.acc_hist) p.acc_hist[p.hist_slot] = scal[1] * inv_batch;
+      DTF_STAMP2(5);
+      if (p.fused && p.global_step) *p.global_step = *p.global_step + 1.0f;
+      DTF_STAMP2(6);
     }
   }
   DTF_STAMP2(7);
+  DTF_BLOCK_STAMP(p.bs, 1);
 }
 
 long long* g_stamps2 = nullptr;
+int g_stamp_block = 1;
+long long* g_block_stamps = nullptr;   // [2*64] forward blocks, then [2*grid] backward blocks
 
 }  // namespace
 
@@ -498,7 +589,7 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
   if (!dtf_step2_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
   const bool fused = mode == DTF_HEAD_FUSED;
-  if (!d->zws || (fused && (!d->shadow || !d->lr))) return DTF_ERR_NULL;
+  if (!d->zws || !d->lr || (fused && !d->shadow)) return DTF_ERR_NULL;
   if (d->batches_per_epoch > 0 && (batch_index < 0 || batch_index >= d->batches_per_epoch))
     return DTF_ERR_SHAPE;
   const int R = ((B + 15) / 16) * 16;
@@ -507,7 +598,7 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   const int tiles_m = (B + 15) / 16, tiles_n = (H + 15) / 16;
   hipLaunchKernelGGL(fwd_tile16_kernel, dim3(tiles_m * tiles_n), dim3(kFwdWaves * 64), 0, stream, d->x,
                      batch_index, d->W1, d->b1, d->W2, d->z2, zacc, zother, R * 16, B, K, H, C, d->act,
-                     fused ? d->shadow : nullptr, d->b2);
+                     fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps});
   BwdParams p;
   p.a2 = d->z2;
   p.zacc = zacc;
@@ -532,11 +623,19 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.global_step = d->global_step;
   p.M = B; p.K = K; p.H = H; p.C = C; p.R = R; p.act = d->act; p.fused = fused ? 1 : 0;
   p.stamps = g_stamps2;
+  p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 64 : nullptr};
   const int tiles_k = (K + 31) / 32, tiles_h = (H + 31) / 32;
-  hipLaunchKernelGGL(bwd_all_kernel, dim3(tiles_k * tiles_h), dim3(kBwdThreads), 0, stream, p);
+  const int duty_blocks = (H + 15) / 16 + 1;
+  p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + duty_blocks + g_stamp_block;
+  hipLaunchKernelGGL(bwd_all_kernel, dim3(tiles_k * tiles_h + duty_blocks), dim3(kBwdThreads), 0, stream, p);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
 // Profiling hook: device buffer of >= 32 int64 receiving {wall_clock64, clock64}
 // at the phase boundaries of the LAST workgroup of bwd_all; null disables.
 extern "C" void dtf_debug_set_bwd_stamps(long long* device_buffer) { g_stamps2 = device_buffer; }
+extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block; }
+
+// Profiling hook: device buffer of >= 2*(64 + backward grid) int64 receiving per-block
+// {start, end} wall-clock stamps of the next two-launch steps; null disables.
+extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }
