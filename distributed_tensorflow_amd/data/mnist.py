@@ -154,7 +154,12 @@ _CACHE = {}
 
 def read_data_sets(train_dir: str = "MNIST_data", one_hot: bool = True, seed: int = 0,
                    shuffle_seed: Optional[int] = None, sizes=(TRAIN_SIZE, VALIDATION_SIZE, TEST_SIZE)) -> Datasets:
-    """Real idx files under ``train_dir`` if present, else the synthetic set (never downloads)."""
+    """Real idx files under ``train_dir`` if present, else the synthetic set (never downloads).
+
+    ``DTF_TRAIN_SIZE=n`` in the environment shrinks the synthetic set (tests of unmodified scripts)."""
+    if sizes == (TRAIN_SIZE, VALIDATION_SIZE, TEST_SIZE) and os.environ.get("DTF_TRAIN_SIZE"):
+        n = int(os.environ["DTF_TRAIN_SIZE"])
+        sizes = (n, max(100, n // 11), max(1000, n // 5))
     n_train, n_val, n_test = sizes
     paths = [_find_idx(train_dir, s) for s in ("train-images-idx3-ubyte", "train-labels-idx1-ubyte",
                                                 "t10k-images-idx3-ubyte", "t10k-labels-idx1-ubyte")]
