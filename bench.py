@@ -29,8 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BASELINE_SINGLE = 55000.0 / 1.3          # samples/s, README.md:15
-BASELINE_MULTI = 3 * 55000.0 / 6.03      # samples/s, README.md:249-251 (mean of 5.75/5.85/6.5 s)
+BASELINE_SINGLE = 55000.0 / 1.3          # samples/s: reference README.md:15 (1.3 s/epoch)
+BASELINE_MULTI = 3 * 55000.0 / 6.03      # samples/s: reference README.md:249-251 (mean of 5.75/5.85/6.5 s)
 BATCH = 100
 STEPS_PER_EPOCH = 550
 

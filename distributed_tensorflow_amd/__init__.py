@@ -4,7 +4,7 @@
 reference scripts are written against (graph building, ``tf.train.*``,
 ``tf.app.flags``, ``tf.summary.*``, ``tf.Session``); the execution underneath is
 PyTorch-ROCm tensors, hand-written gfx950 HIP kernels and RCCL / HIP-IPC /
-native-TCP parameter-server transports.  See README.md and DESIGN.md.
+native-TCP parameter-server transports.
 """
 __version__ = "0.1.0"
 

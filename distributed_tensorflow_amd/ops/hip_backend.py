@@ -88,7 +88,12 @@ def load(required: bool = False) -> Optional[C.CDLL]:
     if _load_error is None:
         try:
             if not _LIB_PATH.exists():
-                raise OSError(f"{_LIB_PATH} not built (run `python -m distributed_tensorflow_amd.build`)")
+                try:   # first use in a fresh checkout: build in-tree (hipcc cross-compiles, no GPU needed)
+                    from .. import build as _build
+
+                    _build.build_hip()
+                except Exception as e:  # noqa: BLE001
+                    raise OSError(f"{_LIB_PATH} not built and the in-tree build failed: {e}") from None
             lib = C.CDLL(str(_LIB_PATH), mode=C.RTLD_GLOBAL)
             _declare(lib)
             _lib = lib

@@ -25,8 +25,22 @@ def cluster_dict(n_ps, n_workers):
     return {"ps": [f"localhost:{p}" for p in ports[:n_ps]], "worker": [f"localhost:{p}" for p in ports[n_ps:]]}
 
 
-def launch_script(script, n_ps, n_workers, extra_args=(), timeout=240, env_extra=None):
-    """Start every task of a cluster as its own process; returns {task: (returncode, output)}."""
+def launch_script(script, n_ps, n_workers, extra_args=(), timeout=240, env_extra=None, attempts=3):
+    """Start every task of a cluster as its own process; returns {task: (returncode, output)}.
+
+    Ports are probed and released before the tasks bind them, so another process can grab one in
+    between; a run that failed to bind or to connect is repeated on fresh ports."""
+    for attempt in range(attempts):
+        out = _launch_once(script, n_ps, n_workers, extra_args, timeout, env_extra)
+        text = "".join(o for _, o in out.values())
+        if all(rc == 0 for rc, _ in out.values()) or attempt == attempts - 1:
+            return out
+        if "cannot bind task server" not in text and "cannot reach task server" not in text:
+            return out
+    return out
+
+
+def _launch_once(script, n_ps, n_workers, extra_args, timeout, env_extra):
     c = cluster_dict(n_ps, n_workers)
     env = dict(os.environ)
     env.update({"DTF_PS_SVRS": ",".join(c["ps"]), "DTF_WORKER_SVRS": ",".join(c["worker"]),

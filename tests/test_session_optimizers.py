@@ -230,3 +230,80 @@ def test_sync_barrier_times_out_with_clear_error_instead_of_hanging():
     finally:
         ps.stop()
         w0.stop()
+
+
+def test_sync_replicas_with_a_backup_worker_drops_the_stale_gradient():
+    """replicas_to_aggregate=2 of total_num_replicas=3: the update uses the first two gradients,
+    the third one (same local_step, arriving after the take) is refused as stale."""
+    from distributed_tensorflow_amd.parallel.store import SHARD_ACC
+
+    cluster = tf.train.ClusterSpec(cluster_dict(1, 3))
+    cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=20000)
+    ps = tf.train.Server(cluster, "ps", 0, config=cfg)
+    ws = [tf.train.Server(cluster, "worker", i, config=cfg) for i in range(3)]
+    try:
+        sessions = []
+        for i in range(3):
+            g = tf.Graph()
+            with g.as_default():
+                with tf.device(tf.train.replica_device_setter(worker_device=f"/job:worker/task:{i}", cluster=cluster)):
+                    m = build_model(0.05)
+                    opt = tf.train.SyncReplicasOptimizer(tf.train.GradientDescentOptimizer(0.05), replicas_to_aggregate=2,
+                                                         total_num_replicas=3, use_locking=True)
+                    m.train_op = opt.minimize(m.cross_entropy, global_step=m.global_step)
+                    m.sync_opt = opt
+            sv = tf.train.Supervisor(graph=g, is_chief=(i == 0), global_step=m.global_step, init_op=m.init_op)
+            sessions.append((sv, sv.prepare_or_wait_for_session(ws[i].target), m))
+        sv0, s0, m0 = sessions[0]
+        assert m0.sync_opt.tokens_per_step == 3
+        sv0.start_queue_runners(s0, [m0.sync_opt.get_chief_queue_runner()])
+        done, errors = [], []
+
+        def work(i, delay):
+            try:
+                import time as _t
+                _t.sleep(delay)
+                sv, sess, m = sessions[i]
+                xx, yy = _batch(20 + i)
+                sess.run(m.train_op, {m.x: xx, m.y_: yy})
+                done.append(i)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        ts = [threading.Thread(target=work, args=(i, 0.0 if i < 2 else 1.0)) for i in range(3)]
+        [t.start() for t in ts]
+        [t.join(60) for t in ts]
+        assert not errors and sorted(done) == [0, 1, 2]
+        assert s0.store.global_step() == 1                         # one aggregate of two gradients
+        assert sessions[2][1].store.dropped == 1                   # the late third gradient was stale
+        count, step, dropped = ws[0].client("ps", 0).acc_info(SHARD_ACC)
+        assert (count, step, dropped) == (0, 1, 1)
+        sv0.request_stop()
+        for sv, s, _ in sessions:
+            s.close()
+            sv.stop()
+    finally:
+        for s in [ps] + ws:
+            s.stop()
+
+
+def test_async_worker_runs_alone_when_its_peer_never_shows_up():
+    """Async mode has no barrier: the chief trains to completion in a 2-worker cluster with one worker missing;
+    the parameter server keeps serving (it is released only when ALL workers have reported done)."""
+    cluster = tf.train.ClusterSpec(cluster_dict(1, 2))
+    cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=5000)
+    ps = tf.train.Server(cluster, "ps", 0, config=cfg)
+    w0 = tf.train.Server(cluster, "worker", 0, config=cfg)
+    try:
+        g, m = _worker_graph(cluster, 0, 0.05, sync=False)
+        sv = tf.train.Supervisor(graph=g, is_chief=True, global_step=m.global_step, init_op=m.init_op)
+        with sv.prepare_or_wait_for_session(w0.target) as sess:
+            xx, yy = _batch(7)
+            for _ in range(5):
+                sess.run(m.train_op, {m.x: xx, m.y_: yy})
+            assert sess.store.global_step() == 5
+        sv.stop()
+        assert ps.join(timeout=0.3) is False
+    finally:
+        ps.stop()
+        w0.stop()
