@@ -198,6 +198,18 @@ class Server:
         host, port = _split_addr(self.cluster.task_address(job, task))
         return rt.StoreClient(_resolvable(host), port, timeout=self.config.operation_timeout_in_ms / 1000.0)
 
+    def report_training_finished(self):
+        """Count this worker's training loop as over (it stops contributing gradients).
+
+        A synchronous chief keeps its aggregator alive until every worker has said so, and sizes
+        the rounds by the workers that have not, so that nobody is stranded at the barrier."""
+        if self.num_ps == 0 or self.job_name != "worker" or getattr(self, "_finished_reported", False):
+            return
+        self._finished_reported = True
+        from .parallel.store import FINISHED_KEY
+
+        self.client("ps", 0).add(FINISHED_KEY, 1)
+
     def report_worker_done(self):
         """Count this worker as finished; the last one releases the parameter servers from join()."""
         if self.num_ps == 0 or not self.config.ps_exit_when_workers_done:

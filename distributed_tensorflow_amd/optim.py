@@ -30,6 +30,7 @@ naming the likely cause instead of the reference's silent hang.
 from __future__ import annotations
 
 import threading
+import time
 from typing import List, Optional, Sequence, Tuple
 
 from . import graph as G
@@ -78,6 +79,9 @@ class QueueRunner:
         self.name = "sync_replicas_chief_queue_runner"
         self.exceptions: List[BaseException] = []
         self.rounds = 0
+        # after the chief's own loop ended: how long to keep waiting for a gradient of the replicas
+        # that have not reported the end of theirs (a crashed replica never will)
+        self.drain_idle_secs = 10.0
 
     def create_threads(self, sess, coord=None, daemon: bool = True, start: bool = False):
         t = threading.Thread(target=self._run, args=(sess, coord), name=self.name, daemon=daemon)
@@ -91,15 +95,35 @@ class QueueRunner:
         if not getattr(store, "is_remote", False):
             return   # a local session aggregates inline
         clients = store.aggregator_clients()
+        required = opt.replicas_to_aggregate
+        idle_since = None
         try:
-            while coord is None or not coord.should_stop():
+            store.begin_aggregation(clients)
+            while True:
+                if coord is not None and coord.should_stop():
+                    idle_since = idle_since or time.time()
+                    if time.time() - idle_since > self.drain_idle_secs:
+                        break
+                    # The chief's own loop is over.  Replicas that still have batches left must not
+                    # be stranded at the barrier: keep aggregating, sized to the replicas still
+                    # training, until every one of them has reported the end of its loop.
+                    live = store.live_workers(clients)
+                    if live <= 0 or live >= store.n_workers:   # all done / nobody reports its end
+                        break
+                    required = max(1, min(opt.replicas_to_aggregate, live))
                 try:
-                    step = store.take_apply_all(clients, opt.replicas_to_aggregate, opt.lr_value(), timeout=0.5)
+                    step = store.take_apply_all(clients, required, opt.lr_value(), timeout=0.5)
                 except TimeoutError:
-                    continue   # re-check the stop flag; the accumulators keep what they have
+                    # nothing to aggregate yet; a replica that finished early no longer counts
+                    live = store.live_workers(clients)
+                    required = max(1, min(opt.replicas_to_aggregate, live if live > 0 else 1))
+                    continue
                 store.enqueue_tokens(clients, step, opt.tokens_per_step)
                 self.rounds += 1
+                idle_since = None
         except BaseException as e:  # surfaced by Supervisor.stop()
+            if coord is not None and coord.should_stop() and isinstance(e, (ConnectionError, OSError, RuntimeError)):
+                return   # the parameter servers went away after the last replica finished
             self.exceptions.append(e)
             if coord is not None:
                 coord.request_stop(e)

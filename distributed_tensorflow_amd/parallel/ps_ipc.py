@@ -15,11 +15,15 @@ from then on move **no tensor bytes through any server**:
                ps task's native server;
 * sync push    the worker copies its gradient into ITS mailbox row next to the
                shard (no atomics, no write conflicts), synchronises its stream
-               and reports arrival to the ps control plane together with its
-               ``local_step`` (stale gradients are refused there); the chief
-               aggregator waits for ``replicas_to_aggregate`` arrivals, applies
-               ``p -= lr/N * sum(mailboxes)`` with N SGD launches on its own
-               stream, bumps ``global_step`` and releases the tokens.
+               and queues an arrival record (worker index, ``local_step``) on
+               the ps control plane; the chief aggregator pops arrivals until
+               it holds the required number of fresh ones (records older than
+               the accumulator step are dropped as stale), applies
+               ``p -= lr/n * sum(their mailboxes)`` with n SGD launches on its
+               own stream, bumps ``global_step`` and deals one token to every
+               worker.  A mailbox is rewritten only after its owner received
+               the token of the round that consumed it, which is why this
+               transport insists on ``replicas_to_aggregate == total_num_replicas``.
 
 This is the path for tasks that share a GPU — RCCL refuses two ranks on one
 device — e.g. "1 PS + 1 worker on one MI355X" and the reference's scenario of a
@@ -41,11 +45,11 @@ import torch
 
 from ..ops import hip_backend as hb
 from ..variables import ShardLayout
-from .store import INIT_KEY, TOKEN_Q
+from .store import FINISHED_KEY, INIT_KEY, spread_tokens, token_key
 
 ALLOC_KEY = "__ipc_alloc__"
 HANDLE_KEY = "__ipc_handle__"
-ARRIVALS = "__ipc_arrivals__"
+ARRIVAL_Q = "__ipc_arrival_q__"
 ACC_STEP = "__ipc_acc_step__"
 LOCK_Q = "__ipc_lock__"
 
@@ -122,7 +126,8 @@ class IpcVariableStore:
         self._gs_off = o - layout.shard_range[self._gs_shard][0]
         self._lr_t = torch.zeros(1, dtype=torch.float32, device=device)
         self._lr_val = None
-        self._agg_round = 0
+        self._arrived: List[int] = []     # aggregator: workers whose mailbox is part of the open round
+        self._acc_step = 0                 # aggregator: rounds applied so far (the accumulator step)
 
     def _c(self, k: int):
         return self.server.client("ps", k)
@@ -214,21 +219,17 @@ class IpcVariableStore:
 
     # -- SyncReplicas protocol ------------------------------------------------------------------
     def push_accumulate(self, grads: torch.Tensor) -> bool:
-        ctl = self._c(self._gs_shard)
-        if self.local_step < ctl.add(ACC_STEP, 0):
-            self.dropped += 1                      # stale: the aggregate for that step is already applied
-            return False
         for k in range(self.n):
             a, b = self.layout.shard_range[k]
             if b > a:
                 self._mailbox(k, self.widx).copy_(grads[a:b], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is counted
-        ctl.add(ARRIVALS, 1)
+        torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is queued
+        self._c(self._gs_shard).qpush(ARRIVAL_Q, struct.pack("<qq", self.widx, self.local_step))
         return True
 
     def dequeue_token(self) -> int:
         try:
-            tok = self._c(self._gs_shard).qpop(TOKEN_Q, timeout=self.timeout)
+            tok = self._c(self._gs_shard).qpop(token_key(self.widx), timeout=self.timeout)
         except TimeoutError:
             raise TimeoutError(
                 f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
@@ -239,34 +240,55 @@ class IpcVariableStore:
     def aggregator_clients(self):
         return [self.server.new_client("ps", k) for k in range(self.n)]
 
+    def live_workers(self, clients) -> int:
+        return self.n_workers - clients[0].add(FINISHED_KEY, 0)
+
+    def begin_aggregation(self, clients):
+        self._acc_step = self.global_step()
+
+    def sync_local_step(self):
+        self.local_step = self.global_step()
+
     def take_apply_all(self, clients, num_required: int, lr: float, timeout: float) -> int:
-        """Chief aggregator: wait for N arrivals, then p -= lr/N * sum(mailboxes) on every shard."""
-        if num_required != self.n_workers:
-            raise NotImplementedError("ipc transport aggregates exactly one gradient per worker "
-                                      "(replicas_to_aggregate must equal the number of workers)")
+        """Chief aggregator: collect num_required fresh arrivals, then p -= lr/n * sum(their mailboxes).
+
+        Resumable: arrivals already popped stay in ``_arrived`` across a TimeoutError.
+        """
+        if num_required > self.n_workers:
+            raise ValueError("replicas_to_aggregate exceeds the number of workers")
         ctl = clients[self._gs_shard]
-        ctl.wait_ge(ARRIVALS, num_required * (self._agg_round + 1), timeout=timeout)
+        deadline = time.time() + timeout
+        while len(self._arrived) < num_required:
+            rec = ctl.qpop(ARRIVAL_Q, timeout=max(0.0, deadline - time.time()))   # raises TimeoutError
+            w, step = struct.unpack("<qq", rec)
+            if step < self._acc_step:
+                self.dropped += 1                  # stale: its round was applied without it
+            elif w not in self._arrived:
+                self._arrived.append(int(w))
         stream = getattr(self, "_agg_stream", None)
         if stream is None:
             stream = self._agg_stream = torch.cuda.Stream(device=self.device)
             self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+        n = len(self._arrived)
         with torch.cuda.stream(stream):
             self._agg_lr.fill_(float(lr))
             for k in range(self.n):
                 if not self.layout.shard_numel(k):
                     continue
                 p = self._params(k)
-                for w in range(self.n_workers):
-                    last = w == self.n_workers - 1
-                    gs = p[self._gs_off:self._gs_off + 1] if (last and k == self._gs_shard) else None
-                    hb.sgd_apply_(p, self._mailbox(k, w), self._agg_lr, 1.0 / num_required, False, gs)
+                for i, w in enumerate(self._arrived):
+                    gs = p[self._gs_off:self._gs_off + 1] if (i == n - 1 and k == self._gs_shard) else None
+                    hb.sgd_apply_(p, self._mailbox(k, w), self._agg_lr, 1.0 / n, False, gs)
         stream.synchronize()
-        self._agg_round += 1
-        ctl.add(ACC_STEP, 1)
+        self._arrived = []
+        self._acc_step += 1
         return self.global_step()
 
     def enqueue_tokens(self, clients, step: int, n: int):
-        clients[self._gs_shard].qpush(TOKEN_Q, struct.pack("<q", int(step)), copies=n)
+        tok = struct.pack("<q", int(step))
+        for w, copies in enumerate(spread_tokens(n, self.n_workers)):
+            if copies:
+                clients[self._gs_shard].qpush(token_key(w), tok, copies=copies)
 
     def global_step(self) -> int:
         torch.cuda.current_stream(self.device).synchronize()

@@ -26,7 +26,17 @@ from ..ops import hip_backend as hb
 from ..variables import ShardLayout
 
 INIT_KEY = "__variables_initialized__"
-TOKEN_Q = "__sync_token_q__"
+TOKEN_Q = "__sync_token_q__"          # + "/<worker index>": every worker owns a token queue
+FINISHED_KEY = "__workers_finished__"   # counter on ps task 0: workers whose training loop has ended
+
+
+def token_key(worker: int) -> str:
+    return f"{TOKEN_Q}/{worker}"
+
+
+def spread_tokens(n: int, n_workers: int) -> List[int]:
+    """How many of n tokens each worker's queue receives (as even as possible)."""
+    return [n // n_workers + (1 if w < n % n_workers else 0) for w in range(n_workers)]
 SHARD_BUF = "shard"
 SHARD_ACC = "shard_acc"
 
@@ -117,6 +127,8 @@ class RemoteVariableStore:
         self._gs_off_in_shard = o - layout.shard_range[self._gs_shard][0]
         self.dropped = 0
         self._agg_pos = 0
+        self.n_workers = max(1, server.num_workers)
+        self.widx = server.task_index
 
     def _c(self, k: int):
         return self.server.client("ps", k)
@@ -191,9 +203,14 @@ class RemoteVariableStore:
         return accepted
 
     def dequeue_token(self) -> int:
-        """Worker: block until the chief released a token; it carries the new global step."""
+        """Worker: block until the chief released this worker's token; it carries the new global step.
+
+        Tokens are dealt one per worker and round, so a fast worker cannot take a slow one's
+        token: with replicas_to_aggregate == total_num_replicas every replica contributes exactly
+        once per update and all of them finish on the same global step.
+        """
         try:
-            tok = self._c(self._gs_shard).qpop(TOKEN_Q, timeout=self.timeout)
+            tok = self._c(self._gs_shard).qpop(token_key(self.widx), timeout=self.timeout)
         except TimeoutError:
             raise TimeoutError(
                 f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
@@ -202,7 +219,30 @@ class RemoteVariableStore:
         return self.local_step
 
     def enqueue_tokens(self, clients, step: int, n: int):
-        clients[self._gs_shard].qpush(TOKEN_Q, struct.pack("<q", int(step)), copies=n)
+        tok = struct.pack("<q", int(step))
+        for w, copies in enumerate(spread_tokens(n, self.n_workers)):
+            if copies:
+                clients[self._gs_shard].qpush(token_key(w), tok, copies=copies)
+
+    def live_workers(self, clients) -> int:
+        """Workers still inside their training loop (the chief aggregator sizes its rounds by this)."""
+        return self.n_workers - clients[0].add(FINISHED_KEY, 0)
+
+    def begin_aggregation(self, clients):
+        """Chief aggregator, once: accumulator steps start at the current global step (a restored run
+        does not start at 0), the base the workers' ``local_step`` tags are compared against."""
+        step = self.global_step_via(clients[self._gs_shard])
+        for k in range(self.n):
+            if self.layout.shard_numel(k):
+                clients[k].acc_set_step(SHARD_ACC, step)
+
+    def global_step_via(self, client) -> int:
+        v = client.buf_read(SHARD_BUF, 1, offset=self._gs_off_in_shard)
+        return int(round(float(v[0])))
+
+    def sync_local_step(self):
+        """Worker, before its first synchronous push: local_step := global_step (TF's local_step_init_op)."""
+        self.local_step = self.global_step()
 
     def take_apply_all(self, clients, num_required: int, lr: float, timeout: float) -> int:
         """Chief aggregator: per shard wait for N gradients and apply their mean; then global_step += 1.

@@ -148,6 +148,7 @@ class Session:
         self._plans: Dict[int, Any] = {}
         self._closed = False
         self.fused_steps = 0
+        self._local_step_ready = False
         self.generic_steps = 0
         if self.config.log_device_placement:
             self._log_placement()
@@ -490,6 +491,9 @@ class Session:
             self.generic_steps += 1
         # ---- push ----
         if sync:
+            if not self._local_step_ready:
+                self.store.sync_local_step()
+                self._local_step_ready = True
             self.store.push_accumulate(self.grad)
             self.store.dequeue_token()
         elif isinstance(opt, SyncReplicasOptimizer):

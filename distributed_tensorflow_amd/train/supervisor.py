@@ -18,8 +18,13 @@ Reference usage (tfdist_between.py:78, 83, 114; tfdist_between_sync.py:81, 87-89
   203, 226, 250-251).
 * with a ``logdir`` the chief runs the standard services: a checkpoint thread
   (every ``save_model_secs``) and a final save in ``stop()``.
-* ``stop()`` also reports the worker as done, which lets the parameter servers
-  leave ``join()`` once every worker has finished.
+* ``request_stop()`` / ``stop()`` report the end of this worker's training loop;
+  a synchronous chief's queue runner keeps aggregating for the replicas that
+  have not finished yet (sized to their number) instead of stranding them at
+  the barrier, which is what happens to the reference's non-chief workers when
+  the chief leaves first.
+* ``stop()`` finally reports the worker as done, which lets the parameter
+  servers leave ``join()`` once every worker has finished.
 """
 from __future__ import annotations
 
@@ -124,6 +129,9 @@ class Supervisor:
                     raise TimeoutError("variables were not initialised by the chief within max_wait_secs")
             if sess.store.is_remote:
                 sess._pull()
+        if sess.store.is_remote:
+            sess.store.sync_local_step()      # local_step := global_step (TF's local_step_init_op)
+            sess._local_step_ready = True
         self._session = sess
         if start_standard_services and self.is_chief and self.logdir:
             self.start_standard_services(sess)
@@ -173,7 +181,16 @@ class Supervisor:
 
     # -- stop -------------------------------------------------------------------------------
     def request_stop(self, ex=None):
+        self._report_finished()
         self.coord.request_stop(ex)
+
+    def _report_finished(self):
+        sess = self._session
+        if sess is not None and sess.server is not None and sess.store.is_remote:
+            try:
+                sess.server.report_training_finished()
+            except Exception:
+                pass
 
     def should_stop(self) -> bool:
         return self.coord.should_stop()
@@ -182,6 +199,7 @@ class Supervisor:
         self.coord.wait_for_stop()
 
     def stop(self, threads=None, close_summary_writer: bool = True):
+        self._report_finished()
         self.coord.request_stop()
         try:
             self.coord.join(threads or self._threads, stop_grace_period_secs=self.stop_grace_secs)

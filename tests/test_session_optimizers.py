@@ -203,7 +203,7 @@ def test_sync_replicas_one_mean_apply_per_n_pushes(n_ps):
             for k in p:
                 torch.testing.assert_close(seen[w][1][k], p[k], rtol=1e-5, atol=1e-6)
         sv0.request_stop()
-        for sv, s, _ in sessions:
+        for sv, s, _ in reversed(sessions):     # the chief's stop() waits for the replicas still training
             s.close()
             sv.stop()
         assert m0.sync_opt.get_chief_queue_runner().rounds == steps
@@ -222,6 +222,7 @@ def test_sync_barrier_times_out_with_clear_error_instead_of_hanging():
         g, m = _worker_graph(cluster, 0, 0.05, sync=True)
         sv = tf.train.Supervisor(graph=g, is_chief=True, global_step=m.global_step, init_op=m.init_op)
         sess = sv.prepare_or_wait_for_session(w0.target)
+        m.sync_opt.get_chief_queue_runner().drain_idle_secs = 0.2
         sv.start_queue_runners(sess, [m.sync_opt.get_chief_queue_runner()])
         xx, yy = _batch(3)
         with pytest.raises(TimeoutError, match="sync barrier"):    # the second replica never pushes
@@ -279,9 +280,53 @@ def test_sync_replicas_with_a_backup_worker_drops_the_stale_gradient():
         count, step, dropped = ws[0].client("ps", 0).acc_info(SHARD_ACC)
         assert (count, step, dropped) == (0, 1, 1)
         sv0.request_stop()
-        for sv, s, _ in sessions:
+        for sv, s, _ in reversed(sessions):
             s.close()
             sv.stop()
+    finally:
+        for s in [ps] + ws:
+            s.stop()
+
+
+def test_sync_chief_keeps_aggregating_for_a_replica_that_has_batches_left():
+    """The chief runs 2 steps and stops; the other replica has 4.  Its last two gradients are
+    aggregated alone (rounds sized to the replicas still training) instead of hanging at the barrier."""
+    cluster = tf.train.ClusterSpec(cluster_dict(1, 2))
+    cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=20000)
+    ps = tf.train.Server(cluster, "ps", 0, config=cfg)
+    ws = [tf.train.Server(cluster, "worker", i, config=cfg) for i in range(2)]
+    try:
+        sessions = []
+        for i in range(2):
+            g, m = _worker_graph(cluster, i, 0.05, sync=True)
+            sv = tf.train.Supervisor(graph=g, is_chief=(i == 0), global_step=m.global_step, init_op=m.init_op)
+            sessions.append((sv, sv.prepare_or_wait_for_session(ws[i].target), m))
+        sv0, s0, m0 = sessions[0]
+        runner = m0.sync_opt.get_chief_queue_runner()
+        sv0.start_queue_runners(s0, [runner])
+        steps_seen, errors = {}, []
+
+        def work(i, n):
+            try:
+                sv, sess, m = sessions[i]
+                out = []
+                for s in range(n):
+                    xx, yy = _batch(40 + 2 * s + i)
+                    out.append(sess.run([m.train_op, m.global_step], {m.x: xx, m.y_: yy})[1])
+                steps_seen[i] = out
+                if i == 0:
+                    sv.request_stop()
+                sv.stop()
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        ts = [threading.Thread(target=work, args=(0, 2)), threading.Thread(target=work, args=(1, 4))]
+        [t.start() for t in ts]
+        [t.join(60) for t in ts]
+        assert not errors, errors
+        assert steps_seen[0] == [0.0, 1.0] and steps_seen[1] == [0.0, 1.0, 2.0, 3.0]
+        assert runner.rounds == 4 and not runner.exceptions
+        assert ps.join(timeout=5.0) is True        # both workers done -> the ps was released
     finally:
         for s in [ps] + ws:
             s.stop()
