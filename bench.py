@@ -40,8 +40,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5500)
     ap.add_argument("--warmup", type=int, default=550)
-    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers"],
-                    help="N=1 default: single; N>1 default: sync (PS shard per GPU, reduce-scatter/all-gather)")
+    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "auto"],
+                    help="N=1 default: single; N>1 default: auto = the faster of sync (PS shard per GPU, "
+                         "reduce-scatter/all-gather) and towers (all-reduce, replicated apply), probed before warm-up")
     ap.add_argument("--chunk", type=int, default=50, help="steps captured per hipGraph replay")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="run the PyTorch reference path on CPU (debug)")

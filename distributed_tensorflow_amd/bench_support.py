@@ -52,33 +52,67 @@ def run_benchmark(args) -> Optional[dict]:
     if distributed:
         dist.init_process_group(backend="gloo" if use_cpu else "nccl",
                                 device_id=None if use_cpu else device)
-    mode = args.mode or ("single" if n == 1 else "sync")
+    mode = args.mode or ("single" if n == 1 else "auto")
 
     sizes = (55000, 5000, 10000) if not use_cpu else (5500, 100, 1000)
     mnist = read_data_sets("MNIST_data", one_hot=True, seed=0, sizes=sizes)
     # Every worker trains on its own independently shuffled copy (tfdist_between.py:92).
     ds = DeviceDataset(mnist.train.images, mnist.train.labels, device, BATCH, seed=1000 + rank)
-    trainer = build_replica_trainer(mode=mode, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
-                                    rank=rank, world=world, chunk=int(args.chunk),
-                                    use_graph=not args.no_graph)
     steps, warmup = int(args.steps), int(args.warmup)
 
-    # Capture the hipGraph chunks outside the timed region.  If capture fails on any rank
-    # (e.g. an RCCL build that cannot be captured) every rank falls back to eager launches.
-    ok = 1
-    try:
-        trainer.prepare(steps_hint=(warmup, steps, STEPS_PER_EPOCH))
-    except Exception as e:  # noqa: BLE001
-        ok = 0
-        print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); using eager launches", flush=True)
-    if distributed:
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
-    if not ok and trainer.use_graph:
-        trainer.use_graph = False
-        trainer._graphs.clear()
-        trainer.engine.reset_step_workspace(trainer.engine.parity)
+    def build(m):
+        return build_replica_trainer(mode=m, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
+                                     rank=rank, world=world, chunk=int(args.chunk),
+                                     use_graph=not args.no_graph)
+
+    def prepare(trainer, hint):
+        # Capture the hipGraph chunks outside the timed region.  If capture fails on any rank
+        # (e.g. an RCCL build that cannot be captured) every rank falls back to eager launches.
+        ok = 1
+        try:
+            trainer.prepare(steps_hint=hint)
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); using eager launches",
+                  flush=True)
+        if distributed:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok and trainer.use_graph:
+            trainer.use_graph = False
+            trainer._graphs.clear()
+            trainer.engine.reset_step_workspace(trainer.engine.parity)
+
+    # Two synchronous data-parallel exchanges compute the same update (the mean gradient applied once):
+    # PS shard per GPU (reduce-scatter -> sharded SGD -> all-gather) and replicated apply after one
+    # all-reduce.  Which one is faster for a 318 KB message is a property of the RCCL build and the
+    # xGMI topology, so "auto" times a short probe of each (untimed, before the warm-up) and keeps the winner.
+    probe_ms = None
+    if mode == "auto":
+        probe = max(2 * int(args.chunk), 100)
+        probe_ms, best = {}, None
+        for cand in ("sync", "towers"):
+            t = build(cand)
+            prepare(t, (probe, probe))
+            t.run_steps(probe)
+            _sync(device, distributed)
+            tp = time.perf_counter()
+            t.run_steps(probe)
+            _sync(device, distributed)
+            dt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=device)
+            if distributed:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)     # identical decision on every rank
+            probe_ms[cand] = round(1000.0 * float(dt.item()) / probe, 5)
+            if best is None or probe_ms[cand] < probe_ms[best[0]]:
+                best = (cand, t)
+            else:
+                t._graphs.clear()
+                del t
+        mode, trainer = best
+    else:
+        trainer = build(mode)
+    prepare(trainer, (warmup, steps, STEPS_PER_EPOCH))
     trainer.run_steps(warmup)
     _sync(device, distributed)
     t0 = time.perf_counter()
@@ -145,6 +179,8 @@ def run_benchmark(args) -> Optional[dict]:
             "last_cost": round(last_cost, 4),
             "global_step": global_step,
         }
+        if probe_ms is not None:
+            result["mode_probe_ms_per_step"] = probe_ms
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,55 @@
+"""bench.py prints one JSON line with the agreed fields, for one process and under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from cluster_utils import free_ports
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+          "vs_baseline", "dtype", "data", "config"}
+
+
+def _json_line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_defaults_to_one_gpu_and_reports_the_contract_fields():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu", "--steps", "30", "--warmup", "5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = _json_line(p.stdout)
+    assert FIELDS <= set(r)
+    assert r["n_gpus"] == 1 and r["steps"] == 30 and r["warmup"] == 5 and r["higher_is_better"] is True
+    assert r["config"]["global_batch"] == 100 and r["scaling"] == "weak" and r["dtype"] == "fp32"
+    assert r["value"] == pytest.approx(100 * 30 / (r["ms_per_step"] * 30 / 1000.0), rel=1e-3)
+    assert r["global_step"] == 35                     # every timed and warm-up step applied its update
+
+
+@pytest.mark.parametrize("mode", [None, "async"])
+def test_two_ranks_over_gloo_report_the_aggregate(mode):
+    port = free_ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu",
+           "--steps", "20", "--warmup", "4"] + (["--mode", mode] if mode else [])
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = _json_line(p.stdout)
+    assert FIELDS <= set(r) and r["n_gpus"] == 2 and r["config"]["global_batch"] == 200
+    assert r["value"] == pytest.approx(2 * 100 * 20 / (r["ms_per_step"] * 20 / 1000.0), rel=1e-3)
+    if mode is None:      # auto: both synchronous exchanges were probed and one was kept
+        assert set(r["mode_probe_ms_per_step"]) == {"sync", "towers"}
+        assert r["global_step"] == 24 + 200           # one update per round of two worker batches (+ probe rounds)
+    else:                 # async rule: every worker's gradient is its own update
+        assert r["global_step"] == 2 * 24
+
+
+def test_gpus_flag_must_match_the_world_size():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu", "--steps", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "torch.distributed.run" in (p.stderr + p.stdout)
