@@ -204,7 +204,21 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
         if sync and is_chief:
             sv.start_queue_runners(sess, [chief_queue_runner])
         writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
-        result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
+        if flags.resident and sync:
+            print("note: synchronous replicas hand-shake with the chief every step and run on the per-batch tier; "
+                  "their device-resident form is `bench.py --mode sync` / parallel.replicas", flush=True)
+        if flags.resident and not sync:
+            from ..data import DeviceDataset
+            from ..parallel.ps_resident import PsResidentTrainer
+
+            ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, flags.batch_size,
+                               seed=1000 + flags.task_index)
+            trainer = PsResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)))
+            trainer.prepare(steps_hint=(ds.batches_per_epoch,))
+            print(trainer.describe(), flush=True)
+            result = run_resident_loop(trainer, mnist, flags, writer, begin_time)
+        else:
+            result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
         if writer is not None:
             writer.close()
         if sync and is_chief:

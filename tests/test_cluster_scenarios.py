@@ -52,6 +52,23 @@ def test_readme_scenario(script, n_ps, n_w, tmp_path):
 
 
 @pytest.mark.slow
+def test_async_workers_on_the_device_resident_tier(tmp_path):
+    """--resident: no per-batch feed; pull, gradient kernels and push per step against the PS shards."""
+    res = launch_script("tfdist_between.py", 2, 2, ARGS[:-1] + ["--resident", f"--logs_path={tmp_path}"])
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    finals = []
+    for i in range(2):
+        out = res[f"worker{i}"][1]
+        assert "between-graph async worker, device-resident" in out
+        steps, costs = _check_worker(out)
+        finals.append(steps[-1])
+    assert max(finals) == 22                                # 2 workers x 11 pushes, every one an update
+    import os
+    assert any(f.startswith("events.out.tfevents.") for f in os.listdir(tmp_path))   # per-step summaries kept
+
+
+@pytest.mark.slow
 def test_single_process_script_both_tiers(tmp_path):
     import os
     import subprocess

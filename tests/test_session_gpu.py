@@ -104,3 +104,27 @@ def test_ipc_transport_gpu_resident_shards(script, n_ps, n_w, tmp_path):
         steps = [int(s) for s in re.findall(r"Step: (\d+),", out)]
         finals.append(steps[-1])
     assert finals == [11] * n_w if "sync" in script else max(finals) == 11 * n_w
+
+
+@pytest.mark.parametrize("n_ps,n_w", [(1, 1), (2, 2)])
+def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, tmp_path):
+    """Separate worker processes, each replaying captured chunks (pull copy, 2 launches, one-sided SGD push)
+    against shards living in the ps tasks' HBM; every push is an update of the shared variables."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.01", "--transport=ipc", "--resident",
+            f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between.py", n_ps, n_w, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    finals, costs = [], []
+    for i in range(n_w):
+        out = res[f"worker{i}"][1]
+        assert "hipGraph chunks" in out, out[-2000:]
+        assert out.rstrip().endswith("Done")
+        finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+    assert max(finals) == 2 * 22 * n_w
+    assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
