@@ -117,8 +117,8 @@ def bwd_stamps(block=1, label="main block 1"):
     torch.cuda.synchronize()
     lib.dtf_debug_set_bwd_stamps(None)
     s = stamps.cpu().view(16, 2)
-    names = ["start", "loads issued", "staged+sync", "logits/softmax+sync", "dW1 mfma loop", "red write+sync",
-             "epilogue", "duties"]
+    names = ["start", "loads issued", "stage+softmax (2 syncs)", "contraction loop", "partials to LDS+sync",
+             "reduce+store", "db1", "end"]
     print("bwd_all phases (%s, thread 0): wall ns / shader cycles" % label)
     for i in range(1, 8):
         print("  %-24s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
@@ -145,14 +145,14 @@ def block_stamps():
     g.replay()
     torch.cuda.synchronize()
     s = stamps.cpu().view(-1, 2)
-    f, b = s[:49], s[64:64 + 108]
+    f, b = s[:49], s[64:64 + 105]   # 100 dW1 tiles + 4 dW2 tiles + 1 statistics block
     t0 = int(f[:, 0].min())
     rel = lambda x: (int(x) - t0) * 10   # noqa: E731
     print("grid timing of the LAST captured step (ns, relative to the first forward block start):")
     print("  fwd  blocks start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
     print("  bwd  blocks start %5d..%5d   end %5d..%5d" % (rel(b[:, 0].min()), rel(b[:, 0].max()), rel(b[:, 1].min()), rel(b[:, 1].max())))
     dur = (b[:, 1] - b[:, 0]) * 10
-    print("  bwd  block durations: min %d median %d max %d; duty blocks (last 8): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-8:]]))
+    print("  bwd  block durations: min %d median %d max %d; duty blocks (last 5): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-5:]]))
     durf = (f[:, 1] - f[:, 0]) * 10
     print("  fwd  block durations: min %d median %d max %d" % (int(durf.min()), int(durf.median()), int(durf.max())))
 

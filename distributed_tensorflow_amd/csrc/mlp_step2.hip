@@ -60,6 +60,11 @@ __device__ __forceinline__ f32x4 ld4_u(const float* __restrict__ p, unsigned off
   return *reinterpret_cast<const f32x4*>(p + off);
 }
 __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+// Same with a 32-bit BYTE offset: base + zext(offset) is exactly the scalar-base + vector-offset
+// addressing form, whatever the compiler can or cannot prove about the element index.
+__device__ __forceinline__ float ld_ub(const float* __restrict__ p, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off);
+}
 __device__ __forceinline__ f32x4 ld4_c(const float* __restrict__ p, int idx, bool ok) {
   return *reinterpret_cast<const f32x4*>(p + (ok ? idx : 0));
 }
@@ -233,7 +238,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
 // Backward: one 32x32 tile of dW1 per workgroup, head recomputed from the logits.
 constexpr int kBwdWaves = 8;
 constexpr int kBwdThreads = kBwdWaves * 64;
-constexpr int kMaxSteps = 8;          // ceil(ceil(128/2)/8) batch-row pairs per wave
 constexpr int kLdw = 17;              // leading dimension of LDS tiles read down a column
 
 struct BwdParams {
@@ -268,37 +272,49 @@ struct BwdParams {
     }                                                                          \
   } while (0)
 
-// Grid = [main blocks: one 32x32 tile of dW1 each] ++ [duty blocks: one 16-row tile of dW2
+// Grid = [main blocks: one 32x32 tile of dW1 each] ++ [duty blocks: one 32-row tile of dW2
 // each, then one block for db2 + step statistics].  Duty blocks run beside the main blocks
 // instead of lengthening some of them.  Every block first rebuilds dz3 for the whole batch
-// from the 6 KB logit accumulator: one THREAD per batch row walks its 10 classes in
-// registers (no cross-lane traffic, ~100 instructions), which is shorter than a
-// lane-parallel softmax with 16-lane reductions.
-constexpr int kLdz = 20;   // dz3s row stride: 16-B aligned rows (broadcast b128 reads), 4-way banks on writes
+// from the 6 KB logit accumulator with four threads per batch row.
+//
+// A dW2 duty block is the main code path with other operands: both are X^T * G products
+// contracted over the batch with 32x32x2 MFMAs, eight waves splitting the batch-row pairs,
+//     main   dW1[k0+i][h0+j] = sum_m x[m][k0+i]  * dz2[m][h0+j]      (dz2 formed in registers)
+//     duty   dW2[h0+i][c=j]  = sum_m a2[m][h0+i] * dz3[m][j]         (dz3 read from LDS)
+// so every block executes the SAME straight-line sequence of global loads (the roles differ
+// only in tile origin; operands a role does not use are valid, harmless reads).  Role-specific
+// loads in separate branches make the compiler drain the memory counter where the branches
+// meet, i.e. a full memory round trip in the middle of the issue phase.
+constexpr int kLdz = 20;   // dz3s row stride: 16-B aligned rows (broadcast b128 reads)
 
+// NJ = batch-row pairs per wave (ceil(ceil(M/2)/8)), CQ = class quads contracted per dz2 element
+// (ceil(C/4)).  Both are compile-time so that the contraction loop is straight-line code: the
+// LDS reads, dot products and MFMAs of different steps overlap instead of running one at a time.
+template <int NJ, int CQ>
 __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[8192 + 128 * kLdz + 32 * kLdw + 128 * kLdw + 64];
+  static_assert(NJ >= 1 && NJ <= 8 && CQ >= 1 && CQ <= 4, "operand slots");
+  __shared__ __attribute__((aligned(16))) float smem[8192 + 128 * kLdz + 32 * kLdw + 256 + 64];
   float* red = smem;                         // [8][16][64] partial tiles (phase 2+)
-  float* zs = smem;                          // [R][17] logits      (phase 1, aliases red)
-  float* ys = smem + 128 * kLdw;             // [R][17] labels      (phase 1, aliases red)
-  float* dz3s = smem + 8192;                 // [R][kLdz]
-  float* w2t = dz3s + 128 * kLdz;            // [32][17] W2 rows of this h tile
-  float* a2d = w2t + 32 * kLdw;              // [R][17] dW2 duty: a2 column tile
-  float* b2s = a2d + 128 * kLdw;             // [16]
+  float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
+  float* ys = smem + 128 * kLdw;             // [128][17] labels    (phase 1, aliases red)
+  float* dz3s = smem + 8192;                 // [128][kLdz]; rows >= M are zero
+  float* w2t = dz3s + 128 * kLdz;            // [32][17] W2 rows of this h tile (zero beyond H / C)
+  float* rowstat = w2t + 32 * kLdw;          // [2][128] per-row loss / correct flag (statistics block)
+  float* b2s = rowstat + 256;                // [16]
   float* db2s = b2s + 16;                    // [16]
   float* scal = db2s + 16;                   // [0] loss sum, [1] correct count
 
   const int R = p.R, H = p.H, C = p.C, M = p.M, K = p.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, q = lane >> 4;
   const int r32 = lane & 31, half = lane >> 5;
   const int tiles_h = (H + 31) >> 5;
   const int n_main = tiles_h * ((K + 31) >> 5);
-  const int h_tiles = (H + 15) >> 4;
   const bool is_main = (int)blockIdx.x < n_main;
-  const int duty = is_main ? -1 : (int)blockIdx.x - n_main;     // 0..h_tiles-1: dW2 tile; h_tiles: db2+stats
-  const bool stats_block = duty == h_tiles;
-  const int th = is_main ? (int)blockIdx.x % tiles_h : 0, tk = is_main ? (int)blockIdx.x / tiles_h : 0;
+  const int duty = (int)blockIdx.x - n_main;                    // 0..tiles_h-1: dW2 tile; tiles_h: db2+stats
+  const bool stats_block = duty == tiles_h;
+  // tile origin: main (k tile, h tile); duty (-, h tile); statistics block: tile 0 (loads unused)
+  const int th = is_main ? (int)blockIdx.x % tiles_h : (stats_block ? 0 : duty);
+  const int tk = is_main ? (int)blockIdx.x / tiles_h : 0;
   const int k0 = tk * 32, h0 = th * 32;
 
   DTF_BLOCK_STAMP(p.bs, 0);
@@ -313,92 +329,91 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   // flight before the first wait.
   // logits + labels, flat [row][16] image: thread element e = tid + u*512 (the accumulator holds
   // 2048 floats, rows >= M are zero: no clamp needed)
-  float zreg[4], yreg[4];
+  //
+  // All byte offsets are computed BEFORE the first load is issued and the order of the loads is
+  // pinned: (1) what phase 1 stages (logits, labels, b2, W2 tile), (2) the contraction operands,
+  // (3) the old values of the outputs.  Loads retire in order, so phase 1 waits only for group 1
+  // while groups 2 and 3 stay in flight behind the softmax.  (Left to itself the scheduler
+  // interleaves address arithmetic with the loads, reuses registers of loads in flight for it and
+  // then has to wait for those loads in the middle of the issue phase.)
   const unsigned y_max = (unsigned)M * C - 1;
+  unsigned yo[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const unsigned e = tid + u * kBwdThreads;
-    zreg[u] = ld_u(p.zacc, e);
-    yreg[u] = ld_u(Y, umin_((e >> 4) * C + (e & 15), y_max));      // masked when staged into LDS
+    yo[u] = umin_((e >> 4) * C + (e & 15), y_max) * 4u;
   }
-  const float b2raw = ld_u(p.b2r, umin_(tid, C - 1));
-  const int nsteps = (M + 1) >> 1;
-  const int kk = k0 + r32, hh = h0 + r32;
-  float xreg[kMaxSteps], areg[kMaxSteps];
-  float wold[2] = {0.f, 0.f};
-  float w2reg = 0.f, b1old = 0.f, w2old = 0.f;
-  float dreg[4] = {0.f, 0.f, 0.f, 0.f};
-  if (is_main) {
-    // W2 rows of this h tile; dW1 operands in MFMA layout (wave w owns batch-row pairs w, w+8, ...)
-    w2reg = ld_u(p.W2r, umin_((h0 + (tid >> 4)) * C + (tid & 15), (unsigned)H * C - 1));   // masked when staged
-    // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
-    // dz2 is 0 there whatever (finite) value was read; tile rows k >= K are never stored.
-    const unsigned kc = umin_(kk, K - 1), hc = umin_(hh, H - 1);
-    const unsigned x_max = (unsigned)(M - 1) * K + kc, a_max = (unsigned)(M - 1) * H + hc;
-    unsigned xo = (2 * wave + half) * K + kc, ao = (2 * wave + half) * H + hc;
+  const unsigned b2o = umin_(tid, C - 1) * 4u;
+  const unsigned w2o = umin_((h0 + (tid >> 4)) * C + (tid & 15), (unsigned)H * C - 1) * 4u;
+  // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
+  // the products are 0 there whatever (finite) value was read; tile rows beyond the output
+  // matrix are never stored.
+  const unsigned kc = umin_(k0 + r32, K - 1), hc = umin_(h0 + r32, H - 1);
+  const unsigned x_max = (unsigned)(M - 1) * K + kc, a_max = (unsigned)(M - 1) * H + hc;
+  unsigned xo[NJ], ao[NJ];
 #pragma unroll
-    for (int j = 0; j < kMaxSteps; ++j) {
-      xreg[j] = ld_u(X, umin_(xo, x_max));
-      areg[j] = ld_u(p.a2, umin_(ao, a_max));
-      xo += 2 * kBwdWaves * K;
-      ao += 2 * kBwdWaves * H;
-    }
-    // fused mode reads the old weights; in gradient mode the same (valid) locations of the
-    // gradient slab are read and ignored, which keeps the loads free of control flow
-    const unsigned w_max = (unsigned)K * H - 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * kBwdThreads;
-      const int g = e >> 6, l = e & 63;
-      const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-      const unsigned ocol = h0 + (l & 31);
-      wold[j] = ld_u(p.oW1, umin_(orow * H + ocol, w_max));
-    }
-    b1old = ld_u(p.ob1, umin_(h0 + (tid & 31), H - 1));
-  } else if (!stats_block) {
-    // dW2 duty: a2 column tile [R][16] and the old W2 tile values
-    const unsigned a_max = (unsigned)M * H - 1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned e = tid + u * kBwdThreads;
-      dreg[u] = ld_u(p.a2, umin_((e >> 4) * H + duty * 16 + (e & 15), a_max));   // masked when staged
-    }
-    {
-      const unsigned h = duty * 16 + 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3), c = tid & 15;
-      w2old = ld_u(p.W2r, umin_(h * C + c, (unsigned)H * C - 1));              // store is guarded
-    }
+  for (int j = 0; j < NJ; ++j) {
+    const unsigned m = 2 * wave + half + 2 * kBwdWaves * j;
+    xo[j] = umin_(m * K + kc, x_max) * 4u;
+    ao[j] = umin_(m * H + hc, a_max) * 4u;
   }
+  // fused mode reads the old weights; in gradient mode the same (valid) locations of the
+  // gradient slab are read and ignored, which keeps the loads free of control flow
+  const unsigned w_max = (unsigned)K * H - 1;
+  unsigned wo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * kBwdThreads;
+    const int g = e >> 6, l = e & 63;
+    const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+    const unsigned ocol = h0 + (l & 31);
+    wo[j] = umin_(orow * H + ocol, w_max) * 4u;
+  }
+  const unsigned b1o = umin_(h0 + (tid & 31), H - 1) * 4u;
+  __builtin_amdgcn_sched_barrier(0);
 
-  DTF_STAMP2(1);
-  // ---- phase 1: stage logits/labels, then softmax-xent with one thread per batch row ----------
+  float zreg[4], yreg[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * kBwdThreads;
-    if (e < R * 16) {
-      const bool ok = (e >> 4) < M && (e & 15) < C;
-      zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
-      ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
-    }
+    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
+    yreg[u] = ld_ub(Y, yo[u]);                                   // masked when staged into LDS
   }
+  const float b2raw = ld_ub(p.b2r, b2o);
+  // W2 rows of the h tile [32][16]: dz2 operand (main), old values of the output tile (duty)
+  const float w2reg = ld_ub(p.W2r, w2o);
+  __builtin_amdgcn_sched_barrier(0);
+  float xreg[NJ], areg[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    xreg[j] = ld_ub(X, xo[j]);
+    areg[j] = ld_ub(p.a2, ao[j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float wold[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wold[j] = ld_ub(p.oW1, wo[j]);
+  const float b1old = ld_ub(p.ob1, b1o);
+  __builtin_amdgcn_sched_barrier(0);
+
+  DTF_STAMP2(1);
+  // ---- phase 1: stage logits/labels, then softmax-xent ----------------------------------------
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * kBwdThreads;       // all 128 rows are staged: rows >= M as zeros
+    const bool ok = (e >> 4) < M && (e & 15) < C;
+    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
+    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
+  }
+  w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + (tid >> 4) < H && (tid & 15) < C) ? w2reg : 0.f;
   if (tid < 16) {
     b2s[tid] = tid < C ? b2raw : 0.f;
     db2s[tid] = 0.f;
-  }
-  if (tid < 4) scal[tid] = 0.f;
-  if (is_main) {
-    w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + (tid >> 4) < H && (tid & 15) < C) ? w2reg : 0.f;
-  } else if (!stats_block) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * kBwdThreads;
-      if (e < R * 16) a2d[(e >> 4) * kLdw + (e & 15)] = ((e >> 4) < M && duty * 16 + (e & 15) < H) ? dreg[u] : 0.f;
-    }
   }
   __syncthreads();
   const float inv_batch = 1.0f / (float)M;
   {
     // four threads per batch row, four classes each; row reductions are two quad-DPP steps
-    const int row = tid >> 2, part = tid & 3;
+    const int row = tid >> 2, part = tid & 3;      // 128 rows: every row of dz3s is written
     const bool row_ok = row < M;
     float z[4], y[4], ex[4];
     float mx = -INFINITY, ysum = 0.f;
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
-    if (row < R) *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
+    *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
     if (stats_block) {   // block-uniform
       const float lse = mx + fast_log(se);
       float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
@@ -447,9 +462,9 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
       argmax_step<kXor2>(bz, az);
       argmax_step<kXor1>(by, ay);
       argmax_step<kXor2>(by, ay);
-      if (part == 0 && row < 128) {
-        a2d[row] = row_ok ? rloss : 0.f;             // a2d is free in the statistics block
-        a2d[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
+      if (part == 0) {
+        rowstat[row] = row_ok ? rloss : 0.f;
+        rowstat[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
       }
     }
   }
@@ -457,31 +472,40 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   DTF_STAMP2(2);
   const float gs = p.grad_scale;
 
-  if (is_main) {
-    // ---- phase 2: dW1 tile; dz2 is formed in registers as the MFMA B operand --------------
-    float w2row[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) w2row[c] = w2t[r32 * kLdw + c];
+  if (!stats_block) {
+    // ---- phase 2: the 32x32 output tile.  Steps beyond the batch need no mask: their dz3 rows
+    // are zero, so both kinds of B operand are exactly 0 there.
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float db1part = 0.f;
+    if (is_main) {
+      float w2row[4 * CQ];
 #pragma unroll
-    for (int j = 0; j < kMaxSteps; ++j) {
-      const int step = wave + j * kBwdWaves;
-      if (step < nsteps) {   // wave-uniform
-        const int m = 2 * step + half;          // < R (R = M rounded up to 16)
+      for (int c = 0; c < 4 * CQ; ++c) w2row[c] = w2t[r32 * kLdw + c];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int m = 2 * (wave + j * kBwdWaves) + half;            // <= 127
         const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + m * kLdz);   // broadcast reads
-        const f32x4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
-        float da = 0.f;
+        float part[CQ];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          da += d0[c] * w2row[c];
-          da += d1[c] * w2row[4 + c];
-          da += d2[c] * w2row[8 + c];
-          da += d3[c] * w2row[12 + c];
+        for (int qd = 0; qd < CQ; ++qd) {       // independent partial sums: short dependency chains
+          const f32x4 d = d4[qd];
+          part[qd] = d[0] * w2row[4 * qd] + d[1] * w2row[4 * qd + 1] + d[2] * w2row[4 * qd + 2] +
+                     d[3] * w2row[4 * qd + 3];
         }
-        const float dz2 = da * dtf_act_bwd(areg[j], p.act);   // areg is 0 outside the valid range
+        float da = part[0];
+#pragma unroll
+        for (int qd = 1; qd < CQ; ++qd) da += part[qd];
+        const float dz2 = da * dtf_act_bwd(areg[j], p.act);
         db1part += dz2;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[j], dz2, acc, 0, 0, 0);
+      }
+    } else {
+      const int cc = r32 < 16 ? r32 : 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int m = 2 * (wave + j * kBwdWaves) + half;
+        const float d = dz3s[m * kLdz + cc];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], r32 < 16 ? d : 0.f, acc, 0, 0, 0);
       }
     }
     DTF_STAMP2(3);
@@ -496,13 +520,18 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 16 + g) * 64 + l];
-      const int orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-      const int ocol = h0 + (l & 31);
-      if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[j] - lr * s : gs * s;
+      const int trow = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), tcol = l & 31;
+      if (is_main) {
+        const int orow = k0 + trow, ocol = h0 + tcol;
+        if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[j] - lr * s : gs * s;
+      } else {
+        const int h = h0 + trow;
+        if (h < H && tcol < C) p.oW2[h * C + tcol] = p.fused ? w2t[trow * kLdw + tcol] - lr * s : gs * s;
+      }
     }
     DTF_STAMP2(5);
     // db1: the workgroups of k-tile 0 see every batch row of their 32 columns
-    if (tk == 0) {
+    if (is_main && tk == 0) {
       __syncthreads();   // red is reused
       db1part += __shfl_xor(db1part, 32);
       if (lane < 32) red[wave * 32 + lane] = db1part;
@@ -515,24 +544,6 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
       }
     }
     DTF_STAMP2(6);
-  } else if (!stats_block) {
-    // ---- duty: dW2[h][c] = sum_b a2[b][h] dz3[b][c] for h in tile `duty`; waves split the batch
-    const float* arow = a2d + q * kLdw + i16;
-    const float* brow = dz3s + q * kLdz + i16;
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = wave * 4; kb < R; kb += kBwdWaves * 4)
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb * kLdw], brow[kb * kLdz], d, 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) red[(wave * 4 + g) * 64 + lane] = d[g];
-    __syncthreads();
-    if (tid < 256) {
-      const int g = tid >> 6, l = tid & 63;
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + g) * 64 + l];
-      const int h = duty * 16 + 4 * (l >> 4) + g, c = l & 15;
-      if (h < H && c < C) p.oW2[h * C + c] = p.fused ? w2old - lr * s : gs * s;
-    }
   } else {
     // ---- duty: db2 and the step statistics -------------------------------------------------
     DTF_STAMP2(3);
@@ -543,8 +554,8 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
       atomicAdd(&db2s[c], s);
     }
     if (wave == 0) {   // sum the per-row loss / correct flags: 2 values per lane, then a wave reduction
-      float l = (lane < R ? a2d[lane] : 0.f) + (lane + 64 < R ? a2d[lane + 64] : 0.f);
-      float k = (lane < R ? a2d[128 + lane] : 0.f) + (lane + 64 < R ? a2d[128 + lane + 64] : 0.f);
+      float l = rowstat[lane] + rowstat[lane + 64];
+      float k = rowstat[128 + lane] + rowstat[128 + lane + 64];
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
         l += __shfl_xor(l, m);
@@ -625,9 +636,15 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.stamps = g_stamps2;
   p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 64 : nullptr};
   const int tiles_k = (K + 31) / 32, tiles_h = (H + 31) / 32;
-  const int duty_blocks = (H + 15) / 16 + 1;
+  const int duty_blocks = tiles_h + 1;
   p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + duty_blocks + g_stamp_block;
-  hipLaunchKernelGGL(bwd_all_kernel, dim3(tiles_k * tiles_h + duty_blocks), dim3(kBwdThreads), 0, stream, p);
+  const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves, cq = (C + 3) / 4;
+  const dim3 grid(tiles_k * tiles_h + duty_blocks), block(kBwdThreads);
+  if (nj <= 7 && cq <= 3) {          // the reference shape: batch 100, 10 classes
+    hipLaunchKernelGGL((bwd_all_kernel<7, 3>), grid, block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((bwd_all_kernel<8, 4>), grid, block, 0, stream, p);
+  }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
