@@ -155,6 +155,8 @@ def block_stamps():
     print("  bwd  block durations: min %d median %d max %d; duty blocks (last 5): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-5:]]))
     durf = (f[:, 1] - f[:, 0]) * 10
     print("  fwd  block durations: min %d median %d max %d" % (int(durf.min()), int(durf.median()), int(durf.max())))
+    print("  fwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(f[i, 0]), rel(f[i, 1])) for i in range(49)))
+    print("  bwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(b[i, 0]), rel(b[i, 1])) for i in range(105)))
 
 
 if __name__ == "__main__":

@@ -126,7 +126,8 @@ struct BlockStamps {
 };
 #define DTF_BLOCK_STAMP(bs, which)                                                        \
   do {                                                                                    \
-    if ((bs).buf && threadIdx.x == 0) (bs).buf[2 * blockIdx.x + (which)] = (long long)wall_clock64(); \
+    if ((bs).buf && threadIdx.x == 0)                                                     \
+      (bs).buf[2 * (blockIdx.y * gridDim.x + blockIdx.x) + (which)] = (long long)wall_clock64(); \
   } while (0)
 
 constexpr int kFwdWaves = 16;
@@ -143,8 +144,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   __shared__ float w2t[16][17];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, q = lane >> 4;
-  const int tiles_n = (H + 15) >> 4;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tn = blockIdx.x, tm = blockIdx.y;     // 2-D grid: no integer division on the way to the first load
   const int m0 = tm * 16, n0 = tn * 16;
   const float* __restrict__ X = xbase + batch_index * (long)M * (long)K;
   const int nms = (K + 15) >> 4;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   const float w2raw = ld_c(W2, (n0 + w_h) * C + w_c, w2_ok);
 
   // block 0: refresh the shadow copy of W2/b2 and clear the other logit accumulator
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
     if (shadow_dst) {
       for (int e = threadIdx.x; e < H * C + C; e += kFwdWaves * 64)
         shadow_dst[e] = e < H * C ? W2[e] : b2[e - H * C];
@@ -234,6 +234,127 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   DTF_BLOCK_STAMP(bs, 1);
 }
 
+// Specialisation for the common shape (K % 4 == 0, K - 256*NMS in [0, 64], H*C + C <= 1024;
+// the reference's 784-100-10 has NMS = 3): straight-line code, ONE memory round trip.
+//   * wave w contracts the full macro-steps w, w+16, ... (NMS of them, none wasted) and ONE
+//     4-wide tail step k = 256*NMS + 4w + q, instead of ceil(K/256) partly empty macro-steps;
+//   * every byte offset is computed before the first load, and the loads are issued back to
+//     back in a pinned order (contraction operands first, epilogue operands last).  In the
+//     generic kernel above the loop header and the vector/scalar load paths make the compiler
+//     wait for earlier loads between macro-steps, i.e. several dependent round trips;
+//   * workgroup 0's extra duties (shadow copy of W2/b2, clearing the other logit accumulator)
+//     take their operands in the same load sequence and store at the very end.
+template <int NMS>
+__global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_fast_kernel(
+    const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
+    const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
+    float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
+  DTF_BLOCK_STAMP(bs, 0);
+  __shared__ float red[kFwdWaves][4][64];
+  __shared__ float a2t[16][17];
+  __shared__ float w2t[64][17];   // rows >= 16 are written (never read) so that the W2 load is used by every thread
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int tn = blockIdx.x, tm = blockIdx.y;     // 2-D grid: no integer division on the way to the first load
+  const int m0 = tm * 16, n0 = tn * 16;
+  const float* __restrict__ X = xbase + batch_index * (long)M * (long)K;
+  const int row = m0 + i16, col = n0 + i16;
+  const bool col_ok = col < H;
+  const unsigned row_c = row < M ? row : M - 1, col_c = col_ok ? col : H - 1;
+
+  // ---- offsets (bytes), all before the first load -------------------------------------------
+  unsigned xo[NMS], wo[NMS][4];
+#pragma unroll
+  for (int j = 0; j < NMS; ++j) {
+    const unsigned kb = (wave + j * kFwdWaves) * 16 + q * 4;     // < 256*NMS <= K: always inside
+    xo[j] = (row_c * K + kb) * 4u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wo[j][s] = ((kb + s) * H + col_c) * 4u;
+  }
+  const unsigned kt = 256u * NMS + 4u * wave + q;                 // tail step: one k per lane quarter
+  const bool kt_ok = kt < (unsigned)K;
+  const unsigned ktc = kt_ok ? kt : K - 1;
+  const unsigned xto = (row_c * K + ktc) * 4u, wto = (ktc * H + col_c) * 4u;
+  // epilogue operands (threads < 256 own one tile element each)
+  const int e_reg = threadIdx.x >> 6, e_lane = threadIdx.x & 63;
+  const int e_col = n0 + (e_lane & 15);
+  const unsigned bo = umin_(col, H - 1) * 4u;     // bias of this lane's column: added to wave 0's partial
+  const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;          // threads < 256: W2 tile element
+  const bool w2_ok = n0 + w_h < H && w_c < C;
+  const unsigned w2o = umin_((n0 + w_h) * C + w_c, (unsigned)H * C - 1) * 4u;
+  // shadow element of this thread (stored by workgroup 0 only): W2 flat, then b2
+  const unsigned se = threadIdx.x, hc = (unsigned)H * C;
+  const bool s_in_w2 = se < hc;
+  const unsigned sow = umin_(se, hc - 1) * 4u, sob = umin_(se - hc, C - 1) * 4u;   // se < hc wraps: clamped
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- loads, back to back ------------------------------------------------------------------
+  f32x4 a[NMS];
+  float bv[NMS][4];
+#pragma unroll
+  for (int j = 0; j < NMS; ++j) {
+    a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + xo[j]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(W, wo[j][s]);
+  }
+  const float at = ld_ub(X, xto);
+  const float bt_raw = ld_ub(W, wto);
+  __builtin_amdgcn_sched_barrier(0);
+  const float bias = ld_ub(b, bo);
+  const float w2raw = ld_ub(W2, w2o);
+  const float sh_w = ld_ub(W2, sow);
+  const float sh_b = ld_ub(b2, sob);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- contraction: columns beyond H and the tail beyond K are masked in B ----------------------
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NMS; ++j) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], col_ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], col_ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], col_ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], col_ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
+  }
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, (col_ok && kt_ok) ? bt_raw : 0.f, acc0, 0, 0, 0);
+  // The bias rides on wave 0's partial sums, so every thread consumes its load here (a load used
+  // only inside the `threadIdx.x < 256` epilogue is sunk there by the compiler: a second round trip).
+  const f32x4 acc = acc0 + acc1;
+  const float badd = wave == 0 ? bias : 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) red[wave][g][lane] = acc[g] + badd;
+  w2t[w_h][w_c] = w2_ok ? w2raw : 0.f;
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFwdWaves; ++w) s += red[w][e_reg][e_lane];
+    const int lrow = 4 * (e_lane >> 4) + e_reg;
+    const int orow = m0 + lrow;
+    float av = 0.f;
+    if (orow < M && e_col < H) {
+      av = fast_act(s, act);
+      out[(long)orow * H + e_col] = av;
+    }
+    a2t[lrow][e_lane & 15] = av;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int lrow = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (m0 + lrow < M && c < C) {
+      float z = 0.f;
+#pragma unroll
+      for (int h = 0; h < 16; ++h) z += a2t[lrow][h] * w2t[h][c];
+      atomicAdd(&zacc[(m0 + lrow) * 16 + c], z);
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (shadow_dst && se < hc + C) shadow_dst[se] = s_in_w2 ? sh_w : sh_b;
+    for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
+  }
+  DTF_BLOCK_STAMP(bs, 1);
+}
+
 // ---------------------------------------------------------------------------
 // Backward: one 32x32 tile of dW1 per workgroup, head recomputed from the logits.
 constexpr int kBwdWaves = 8;
@@ -266,7 +387,7 @@ struct BwdParams {
 
 #define DTF_STAMP2(i)                                                          \
   do {                                                                         \
-    if (p.stamps && threadIdx.x == 0 && (int)blockIdx.x == p.stamp_block) {    \
+    if (p.stamps && threadIdx.x == 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) == p.stamp_block) { \
       p.stamps[2 * (i)] = (long long)wall_clock64();                           \
       p.stamps[2 * (i) + 1] = (long long)clock64();                            \
     }                                                                          \
@@ -307,14 +428,13 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   const int R = p.R, H = p.H, C = p.C, M = p.M, K = p.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, half = lane >> 5;
-  const int tiles_h = (H + 31) >> 5;
-  const int n_main = tiles_h * ((K + 31) >> 5);
-  const bool is_main = (int)blockIdx.x < n_main;
-  const int duty = (int)blockIdx.x - n_main;                    // 0..tiles_h-1: dW2 tile; tiles_h: db2+stats
-  const bool stats_block = duty == tiles_h;
-  // tile origin: main (k tile, h tile); duty (-, h tile); statistics block: tile 0 (loads unused)
-  const int th = is_main ? (int)blockIdx.x % tiles_h : (stats_block ? 0 : duty);
-  const int tk = is_main ? (int)blockIdx.x / tiles_h : 0;
+  // 2-D grid (no integer division): x = h tile; y < tiles_k: dW1 tile row y; y == tiles_k: dW2
+  // tile x; y == tiles_k + 1: the statistics block (x == 0; its tile loads are unused).
+  const int tiles_k = (K + 31) >> 5;
+  const bool is_main = (int)blockIdx.y < tiles_k;
+  const bool stats_block = (int)blockIdx.y == tiles_k + 1;
+  if (stats_block && blockIdx.x != 0) return;
+  const int th = blockIdx.x, tk = is_main ? (int)blockIdx.y : 0;
   const int k0 = tk * 32, h0 = th * 32;
 
   DTF_BLOCK_STAMP(p.bs, 0);
@@ -336,42 +456,19 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   // while groups 2 and 3 stay in flight behind the softmax.  (Left to itself the scheduler
   // interleaves address arithmetic with the loads, reuses registers of loads in flight for it and
   // then has to wait for those loads in the middle of the issue phase.)
+  // Offsets use 24-bit multiplies (one v_mad_u32_u24 each; every index is far below 2^24): a
+  // generic 32-bit multiply-add becomes a 64-bit mad whose unused high half the register
+  // allocator may place on a load still in flight, which costs a wait in the issue phase.
   const unsigned y_max = (unsigned)M * C - 1;
   unsigned yo[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const unsigned e = tid + u * kBwdThreads;
-    yo[u] = umin_((e >> 4) * C + (e & 15), y_max) * 4u;
+    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
   }
   const unsigned b2o = umin_(tid, C - 1) * 4u;
-  const unsigned w2o = umin_((h0 + (tid >> 4)) * C + (tid & 15), (unsigned)H * C - 1) * 4u;
-  // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
-  // the products are 0 there whatever (finite) value was read; tile rows beyond the output
-  // matrix are never stored.
-  const unsigned kc = umin_(k0 + r32, K - 1), hc = umin_(h0 + r32, H - 1);
-  const unsigned x_max = (unsigned)(M - 1) * K + kc, a_max = (unsigned)(M - 1) * H + hc;
-  unsigned xo[NJ], ao[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const unsigned m = 2 * wave + half + 2 * kBwdWaves * j;
-    xo[j] = umin_(m * K + kc, x_max) * 4u;
-    ao[j] = umin_(m * H + hc, a_max) * 4u;
-  }
-  // fused mode reads the old weights; in gradient mode the same (valid) locations of the
-  // gradient slab are read and ignored, which keeps the loads free of control flow
-  const unsigned w_max = (unsigned)K * H - 1;
-  unsigned wo[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * kBwdThreads;
-    const int g = e >> 6, l = e & 63;
-    const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-    const unsigned ocol = h0 + (l & 31);
-    wo[j] = umin_(orow * H + ocol, w_max) * 4u;
-  }
-  const unsigned b1o = umin_(h0 + (tid & 31), H - 1) * 4u;
+  const unsigned w2o = umin_(__umul24(h0 + (tid >> 4), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
   __builtin_amdgcn_sched_barrier(0);
-
   float zreg[4], yreg[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -382,12 +479,43 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   // W2 rows of the h tile [32][16]: dz2 operand (main), old values of the output tile (duty)
   const float w2reg = ld_ub(p.W2r, w2o);
   __builtin_amdgcn_sched_barrier(0);
+
+  // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
+  // the products are 0 there whatever (finite) value was read; tile rows beyond the output
+  // matrix are never stored.  Byte offsets advance by a constant per step: add + min per load.
+  const unsigned kc = umin_(k0 + r32, K - 1), hc = umin_(h0 + r32, H - 1);
+  const unsigned x_max4 = (__umul24(M - 1, K) + kc) * 4u, a_max4 = (__umul24(M - 1, H) + hc) * 4u;
+  const unsigned m0r = 2 * wave + half;
+  const unsigned x_base4 = (__umul24(m0r, K) + kc) * 4u, a_base4 = (__umul24(m0r, H) + hc) * 4u;
+  const unsigned x_step4 = 8u * kBwdWaves * K, a_step4 = 8u * kBwdWaves * H;      // 2*waves rows, in bytes
+  unsigned xo[NJ], ao[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    xo[j] = umin_(x_base4 + j * x_step4, x_max4);
+    ao[j] = umin_(a_base4 + j * a_step4, a_max4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float xreg[NJ], areg[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     xreg[j] = ld_ub(X, xo[j]);
     areg[j] = ld_ub(p.a2, ao[j]);
   }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // fused mode reads the old weights; in gradient mode the same (valid) locations of the
+  // gradient slab are read and ignored, which keeps the loads free of control flow
+  const unsigned w_max = (unsigned)K * H - 1;
+  unsigned wo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * kBwdThreads;
+    const int g = e >> 6, l = e & 63;
+    const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+    const unsigned ocol = h0 + (l & 31);
+    wo[j] = umin_(__umul24(orow, H) + ocol, w_max) * 4u;
+  }
+  const unsigned b1o = umin_(h0 + (tid & 31), H - 1) * 4u;
   __builtin_amdgcn_sched_barrier(0);
   float wold[2];
 #pragma unroll
@@ -607,9 +735,23 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   float* zacc = d->zws + (parity & 1) * 2048;
   float* zother = d->zws + ((parity & 1) ^ 1) * 2048;
   const int tiles_m = (B + 15) / 16, tiles_n = (H + 15) / 16;
-  hipLaunchKernelGGL(fwd_tile16_kernel, dim3(tiles_m * tiles_n), dim3(kFwdWaves * 64), 0, stream, d->x,
-                     batch_index, d->W1, d->b1, d->W2, d->z2, zacc, zother, R * 16, B, K, H, C, d->act,
-                     fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps});
+  const int nms_full = K / 256, k_tail = K - 256 * nms_full;
+  const bool fast_fwd = (K & 3) == 0 && nms_full >= 1 && nms_full <= 4 && k_tail <= 64 && H * C + C <= kFwdWaves * 64;
+#define DTF_FWD_ARGS                                                                                   \
+  dim3(tiles_n, tiles_m), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
+      zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
+  if (fast_fwd && nms_full == 3) {
+    hipLaunchKernelGGL((fwd_tile16_fast_kernel<3>), DTF_FWD_ARGS);
+  } else if (fast_fwd && nms_full == 1) {
+    hipLaunchKernelGGL((fwd_tile16_fast_kernel<1>), DTF_FWD_ARGS);
+  } else if (fast_fwd && nms_full == 2) {
+    hipLaunchKernelGGL((fwd_tile16_fast_kernel<2>), DTF_FWD_ARGS);
+  } else if (fast_fwd && nms_full == 4) {
+    hipLaunchKernelGGL((fwd_tile16_fast_kernel<4>), DTF_FWD_ARGS);
+  } else {
+    hipLaunchKernelGGL(fwd_tile16_kernel, DTF_FWD_ARGS);
+  }
+#undef DTF_FWD_ARGS
   BwdParams p;
   p.a2 = d->z2;
   p.zacc = zacc;
@@ -637,9 +779,10 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 64 : nullptr};
   const int tiles_k = (K + 31) / 32, tiles_h = (H + 31) / 32;
   const int duty_blocks = tiles_h + 1;
+  // linear ids: dW1 tiles, then dW2 tiles, then the statistics block (negative: counted from it backwards)
   p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + duty_blocks + g_stamp_block;
   const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves, cq = (C + 3) / 4;
-  const dim3 grid(tiles_k * tiles_h + duty_blocks), block(kBwdThreads);
+  const dim3 grid(tiles_h, tiles_k + 2), block(kBwdThreads);
   if (nj <= 7 && cq <= 3) {          // the reference shape: batch 100, 10 classes
     hipLaunchKernelGGL((bwd_all_kernel<7, 3>), grid, block, 0, stream, p);
   } else {
