@@ -355,6 +355,131 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_fast_kernel(
   DTF_BLOCK_STAMP(bs, 1);
 }
 
+// Forward with 8x8 output tiles: twice the workgroups in each direction (13 x 13 = 169 for
+// 100 x 100), each ingesting half as many rows of x and half as many columns of W: 2 x 25 KB
+// instead of 2 x 50 KB.  A CU ingests a cold stream at only 40-60 GB/s, so the bytes per
+// workgroup set the length of the kernel; the chip has 256 CUs and the 16x16 tiling uses 49.
+//
+// One 16x16x4 MFMA serves an 8x8 tile by contracting TWO k ranges at once on its diagonal:
+//     A rows 0-7  = x[m0+r][k in range 0]     B cols 0-7  = W[k in range 0][n0+c]
+//     A rows 8-15 = x[m0+r][k in range 1]     B cols 8-15 = W[k in range 1][n0+c]
+// D[0:8,0:8] and D[8:16,8:16] are the two partial products (the off-diagonal blocks are cross
+// terms and are ignored), so every loaded element is used and no lane loads padding.
+// Lane (i = l & 15, q = l >> 4): r = i & 7, g = i >> 3; slot j of wave w contracts macro-step
+// ms = 2 (w + 16 j) + g, k = 16 ms + 4 q + s for MFMA s (one 16-B load of x per slot).
+template <int NS>
+__global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
+    const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
+    const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
+    float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
+  DTF_BLOCK_STAMP(bs, 0);
+  __shared__ float red[kFwdWaves][4][64];
+  __shared__ float psum[2][64];
+  __shared__ float a2t[8][9];
+  __shared__ float w2t[64][17];   // rows >= 8 are written (never read) so that the W2 load is used by every thread
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int r8 = i16 & 7, g = i16 >> 3;
+  const int tn = blockIdx.x, tm = blockIdx.y;
+  const int m0 = tm * 8, n0 = tn * 8;
+  const float* __restrict__ X = xbase + batch_index * (long)M * (long)K;
+  const int row = m0 + r8, col = n0 + r8;
+  const bool col_ok = col < H;
+  const unsigned row_c = row < M ? row : M - 1, col_c = col_ok ? col : H - 1;
+
+  // ---- offsets (bytes), all before the first load -------------------------------------------
+  unsigned xo[NS], wo[NS][4];
+  bool kok[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const unsigned kb = (2u * (wave + j * kFwdWaves) + g) * 16u + q * 4u;
+    kok[j] = kb < (unsigned)K;                       // K % 4 == 0: a quarter is inside or outside as a whole
+    const unsigned kbc = kok[j] ? kb : K - 4;
+    xo[j] = (__umul24(row_c, K) + kbc) * 4u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wo[j][s] = (__umul24(kbc + s, H) + col_c) * 4u;
+  }
+  const unsigned bo = umin_(col, H - 1) * 4u;          // bias of this lane's column
+  const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;           // threads < 128: W2 tile element
+  const bool w2_ok = w_h < 8 && n0 + w_h < H && w_c < C;
+  const unsigned w2o = umin_(__umul24(n0 + (w_h & 7), C) + w_c, (unsigned)H * C - 1) * 4u;
+  const unsigned se = threadIdx.x, hc = (unsigned)H * C;
+  const bool s_in_w2 = se < hc;
+  const unsigned sow = umin_(se, hc - 1) * 4u, sob = umin_(se - hc, C - 1) * 4u;   // se < hc wraps: clamped
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- loads, back to back ------------------------------------------------------------------
+  f32x4 a[NS];
+  float bv[NS][4];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + xo[j]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(W, wo[j][s]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const float bias = ld_ub(b, bo);
+  const float w2raw = ld_ub(W2, w2o);
+  const float sh_w = ld_ub(W2, sow);
+  const float sh_b = ld_ub(b2, sob);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- contraction ------------------------------------------------------------------------------
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const bool ok = col_ok && kok[j];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
+  }
+  // D[row = 4q + reg][col = i16].  The bias rides once on wave 0's first diagonal block.
+  const f32x4 acc = acc0 + acc1;
+  const float badd = (wave == 0 && g == 0) ? bias : 0.f;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) red[wave][rg][lane] = acc[rg] + badd;
+  w2t[w_h][w_c] = w2_ok ? w2raw : 0.f;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    // thread (blk, r, c): the sum over the 16 waves of diagonal block blk, element (r, c)
+    const int blk = threadIdx.x >> 6, r = (threadIdx.x >> 3) & 7, c = threadIdx.x & 7;
+    const int drow = 8 * blk + r, dcol = 8 * blk + c;
+    const int rg = drow & 3, ln = ((drow >> 2) << 4) | dcol;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kFwdWaves; ++w) s += red[w][rg][ln];
+    psum[blk][threadIdx.x & 63] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const int orow = m0 + r, ocol = n0 + c;
+    float av = 0.f;
+    if (orow < M && ocol < H) {
+      av = fast_act(psum[0][threadIdx.x] + psum[1][threadIdx.x], act);
+      out[(long)orow * H + ocol] = av;
+    }
+    a2t[r][c] = av;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (m0 + r < M && c < C) {
+      float z = 0.f;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) z += a2t[r][h] * w2t[h][c];
+      atomicAdd(&zacc[(m0 + r) * 16 + c], z);
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (shadow_dst && se < hc + C) shadow_dst[se] = s_in_w2 ? sh_w : sh_b;
+    for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
+  }
+  DTF_BLOCK_STAMP(bs, 1);
+}
+
 // ---------------------------------------------------------------------------
 // Backward: one 32x32 tile of dW1 per workgroup, head recomputed from the logits.
 constexpr int kBwdWaves = 8;
@@ -709,9 +834,10 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   DTF_BLOCK_STAMP(p.bs, 1);
 }
 
+bool g_fwd_tile8 = true;
 long long* g_stamps2 = nullptr;
 int g_stamp_block = 1;
-long long* g_block_stamps = nullptr;   // [2*64] forward blocks, then [2*grid] backward blocks
+long long* g_block_stamps = nullptr;   // [2*256] forward blocks, then [2*grid] backward blocks
 
 }  // namespace
 
@@ -740,7 +866,20 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
 #define DTF_FWD_ARGS                                                                                   \
   dim3(tiles_n, tiles_m), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
-  if (fast_fwd && nms_full == 3) {
+  const int ns8 = ((K + 15) / 16 + 31) / 32;   // slots of the 8x8 tiling: 32 macro-steps per slot
+  const bool tile8 = g_fwd_tile8 && (K & 3) == 0 && K >= 16 && ns8 <= 4 && H * C + C <= kFwdWaves * 64;
+#define DTF_FWD8_ARGS                                                                                 \
+  dim3((H + 7) / 8, (B + 7) / 8), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
+      zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
+  if (tile8 && ns8 == 2) {
+    hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_FWD8_ARGS);
+  } else if (tile8 && ns8 == 1) {
+    hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_FWD8_ARGS);
+  } else if (tile8 && ns8 == 3) {
+    hipLaunchKernelGGL((fwd_tile8_kernel<3>), DTF_FWD8_ARGS);
+  } else if (tile8 && ns8 == 4) {
+    hipLaunchKernelGGL((fwd_tile8_kernel<4>), DTF_FWD8_ARGS);
+  } else if (fast_fwd && nms_full == 3) {
     hipLaunchKernelGGL((fwd_tile16_fast_kernel<3>), DTF_FWD_ARGS);
   } else if (fast_fwd && nms_full == 1) {
     hipLaunchKernelGGL((fwd_tile16_fast_kernel<1>), DTF_FWD_ARGS);
@@ -752,6 +891,7 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
     hipLaunchKernelGGL(fwd_tile16_kernel, DTF_FWD_ARGS);
   }
 #undef DTF_FWD_ARGS
+#undef DTF_FWD8_ARGS
   BwdParams p;
   p.a2 = d->z2;
   p.zacc = zacc;
@@ -776,7 +916,7 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.global_step = d->global_step;
   p.M = B; p.K = K; p.H = H; p.C = C; p.R = R; p.act = d->act; p.fused = fused ? 1 : 0;
   p.stamps = g_stamps2;
-  p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 64 : nullptr};
+  p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 256 : nullptr};
   const int tiles_k = (K + 31) / 32, tiles_h = (H + 31) / 32;
   const int duty_blocks = tiles_h + 1;
   // linear ids: dW1 tiles, then dW2 tiles, then the statistics block (negative: counted from it backwards)
@@ -791,11 +931,14 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
+// Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.
+extern "C" void dtf_debug_set_fwd_tile8(int on) { g_fwd_tile8 = on != 0; }
+
 // Profiling hook: device buffer of >= 32 int64 receiving {wall_clock64, clock64}
 // at the phase boundaries of the LAST workgroup of bwd_all; null disables.
 extern "C" void dtf_debug_set_bwd_stamps(long long* device_buffer) { g_stamps2 = device_buffer; }
 extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block; }
 
-// Profiling hook: device buffer of >= 2*(64 + backward grid) int64 receiving per-block
+// Profiling hook: device buffer of >= 2*(256 + backward grid) int64 receiving per-block
 // {start, end} wall-clock stamps of the next two-launch steps; null disables.
 extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }

@@ -73,6 +73,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_hip_build_info.restype = C.c_char_p
     lib.dtf_debug_force_generic_path.argtypes = [i32]
     lib.dtf_debug_force_generic_path.restype = None
+    lib.dtf_debug_set_fwd_tile8.argtypes = [i32]
+    lib.dtf_debug_set_fwd_tile8.restype = None
     lib.dtf_debug_set_head_stamps.argtypes = [vp]
     lib.dtf_debug_set_head_stamps.restype = None
     for name in ("dtf_mlp_step_fused", "dtf_mlp_step_grad", "dtf_advance_cursor", "dtf_mlp_eval",
@@ -262,3 +264,8 @@ def build_info() -> str:
 def force_generic_path(on: bool):
     """Route steps through the generic three-launch kernels even where the two-launch path applies."""
     require().dtf_debug_force_generic_path(1 if on else 0)
+
+
+def set_forward_tile8(on: bool):
+    """Two-launch path: forward with 8x8 output tiles (default) or with 16x16 tiles."""
+    require().dtf_debug_set_fwd_tile8(1 if on else 0)

@@ -114,12 +114,15 @@ def _engine(device, B=100, K=784, H=100, C=10, act="sigmoid", with_grads=True, s
     return eng
 
 
-@pytest.fixture(params=["two_launch", "generic"])
+@pytest.fixture(params=["two_launch", "two_launch_tile16", "generic"])
 def step_path(request):
-    """Both step implementations: the 2-launch small-batch path and the generic 3-launch path."""
+    """Every step implementation: the 2-launch small-batch path with either forward tiling (8x8 tiles,
+    the default, and 16x16 tiles) and the generic 3-launch path."""
     hb.force_generic_path(request.param == "generic")
+    hb.set_forward_tile8(request.param != "two_launch_tile16")
     yield request.param
     hb.force_generic_path(False)
+    hb.set_forward_tile8(True)
 
 
 @pytest.mark.parametrize("B,K,H,C,act", [(100, 784, 100, 10, "sigmoid"), (100, 784, 100, 10, "relu"),
