@@ -129,7 +129,7 @@ def block_stamps():
     eng = make_engine()
     lib = hb.require()
     d = eng._descriptor()
-    n = 2 * (256 + 128)
+    n = 2 * (256 + 256)
     stamps = torch.zeros(n, dtype=torch.int64, device="cuda")
     lib.dtf_debug_set_block_stamps.argtypes = [C.c_void_p]
     lib.dtf_debug_set_block_stamps.restype = None
@@ -146,18 +146,19 @@ def block_stamps():
     torch.cuda.synchronize()
     s = stamps.cpu().view(-1, 2)
     nf = int((s[:256, 0] != 0).sum())
-    f, b = s[:nf], s[256:256 + 105]   # 100 dW1 tiles + 4 dW2 tiles + 1 statistics block
+    nb = int((s[256:, 0] != 0).sum())
+    f, b = s[:nf], s[256:256 + nb]   # 100 dW1 tiles + 4 dW2 tiles + 1 statistics block
     t0 = int(f[:, 0].min())
     rel = lambda x: (int(x) - t0) * 10   # noqa: E731
     print("grid timing of the LAST captured step (ns, relative to the first forward block start):")
     print("  fwd  blocks start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
     print("  bwd  blocks start %5d..%5d   end %5d..%5d" % (rel(b[:, 0].min()), rel(b[:, 0].max()), rel(b[:, 1].min()), rel(b[:, 1].max())))
     dur = (b[:, 1] - b[:, 0]) * 10
-    print("  bwd  block durations: min %d median %d max %d; duty blocks (last 5): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-5:]]))
+    print("  bwd  block durations: min %d median %d max %d; last 8 blocks (dW2 tiles, statistics): %s" % (int(dur.min()), int(dur.median()), int(dur.max()), [int(x) for x in dur[-8:]]))
     durf = (f[:, 1] - f[:, 0]) * 10
     print("  fwd  block durations: min %d median %d max %d" % (int(durf.min()), int(durf.median()), int(durf.max())))
     print("  fwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(f[i, 0]), rel(f[i, 1])) for i in range(nf)))
-    print("  bwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(b[i, 0]), rel(b[i, 1])) for i in range(105)))
+    print("  bwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(b[i, 0]), rel(b[i, 1])) for i in range(nb)))
 
 
 if __name__ == "__main__":

@@ -834,6 +834,298 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
   DTF_BLOCK_STAMP(p.bs, 1);
 }
 
+// Backward with 32(k) x 16(h) tiles of dW1: 175 + 7 + 1 workgroups instead of 100 + 4 + 1, each
+// ingesting ~40 KB instead of ~55 KB (same reasoning as the 8x8 forward tiling: the bytes a CU
+// has to pull in from cold caches set the length of the kernel).  16x16x4 MFMAs, lane
+// (i = l & 15, q = l >> 4), wave w contracts batch-row quads w, w+8, ... (row m = 4 quad + q):
+//     main   dW1[k0+16s+i][h0+j] = sum_m x[m][k0+16s+i] * dz2[m][h0+j]     (s = 0, 1: two A tiles, one B)
+//     duty   dW2[h0+i][c=j]      = sum_m a2[m][h0+i]    * dz3[m][j]
+// The a2 operand has the same lane mapping in both roles, so — as in bwd_all_kernel — every
+// block executes one straight-line sequence of loads.  dz2 is formed once per (row, column)
+// and feeds both MFMAs: half the dot products of the 32x32 tiling.
+template <int NS, int CQ>
+__global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
+  static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4, "operand slots");
+  __shared__ __attribute__((aligned(16))) float smem[2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 256 + 64];
+  float* red = smem;                         // [8 waves][8][64] partial tiles (phase 2+)
+  float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
+  float* ys = smem + 128 * kLdw;             // [128][17] labels    (phase 1, aliases red)
+  float* dz3s = smem + 2 * 128 * kLdw;       // [128][kLdz]; rows >= M are zero
+  float* w2t = dz3s + 128 * kLdz;            // [32][17]: rows 0-15 = W2 rows of this h tile (zero beyond H / C)
+  float* rowstat = w2t + 32 * kLdw;          // [2][128] per-row loss / correct flag (statistics block)
+  float* b2s = rowstat + 256;                // [16]
+  float* db2s = b2s + 16;                    // [16]
+  float* scal = db2s + 16;                   // [0] loss sum, [1] correct count
+
+  const int R = p.R, H = p.H, C = p.C, M = p.M, K = p.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  // 2-D grid: x = h tile (16 columns); y < tiles_k: dW1 tile row y (32 rows); y == tiles_k: dW2
+  // tile x; y == tiles_k + 1: the statistics block (x == 0; its tile loads are unused).
+  const int tiles_k = (K + 31) >> 5;
+  const bool is_main = (int)blockIdx.y < tiles_k;
+  const bool stats_block = (int)blockIdx.y == tiles_k + 1;
+  if (stats_block && blockIdx.x != 0) return;
+  const int th = blockIdx.x, tk = is_main ? (int)blockIdx.y : 0;
+  const int k0 = tk * 32, h0 = th * 16;
+
+  DTF_BLOCK_STAMP(p.bs, 0);
+  DTF_STAMP2(0);
+  // ---- phase 0: three pinned groups of loads, offsets of a group computed just before it ------
+  const float* __restrict__ X = p.xbase + p.batch_index * (long)M * (long)K;
+  const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;
+  const float lr = *p.lr;
+  const unsigned y_max = (unsigned)M * C - 1;
+  unsigned yo[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned e = tid + u * kBwdThreads;
+    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
+  }
+  const unsigned b2o = umin_(tid, C - 1) * 4u;
+  const unsigned w2o = umin_(__umul24(h0 + ((tid >> 4) & 15), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
+  __builtin_amdgcn_sched_barrier(0);
+  float zreg[4], yreg[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
+    yreg[u] = ld_ub(Y, yo[u]);
+  }
+  const float b2raw = ld_ub(p.b2r, b2o);
+  const float w2reg = ld_ub(p.W2r, w2o);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // operands stay unmasked: rows >= M meet dz3 == 0, columns >= H meet W2 == 0
+  const unsigned kc0 = umin_(k0 + i16, K - 1), kc1 = umin_(k0 + 16 + i16, K - 1), hc = umin_(h0 + i16, H - 1);
+  const unsigned m0r = 4 * wave + q;
+  const unsigned rowK4 = __umul24(m0r, K) * 4u, maxK4 = __umul24(M - 1, K) * 4u;
+  const unsigned a_base4 = (__umul24(m0r, H) + hc) * 4u, a_max4 = (__umul24(M - 1, H) + hc) * 4u;
+  const unsigned x_step4 = 16u * kBwdWaves * K, a_step4 = 16u * kBwdWaves * H;     // 4*waves rows, in bytes
+  unsigned xo0[NS], xo1[NS], ao[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const unsigned rk = umin_(rowK4 + j * x_step4, maxK4);
+    xo0[j] = rk + kc0 * 4u;
+    xo1[j] = rk + kc1 * 4u;
+    ao[j] = umin_(a_base4 + j * a_step4, a_max4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float x0[NS], x1[NS], areg[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    x0[j] = ld_ub(X, xo0[j]);
+    x1[j] = ld_ub(X, xo1[j]);
+    areg[j] = ld_ub(p.a2, ao[j]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // output element of this thread after the cross-wave reduction: sub-tile, register, lane
+  const int o_sub = tid >> 8, o_reg = (tid >> 6) & 3, o_ln = tid & 63;
+  const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
+  const unsigned wo = umin_(__umul24(k0 + o_trow, H) + h0 + o_tcol, (unsigned)K * H - 1) * 4u;
+  const unsigned b1o = umin_(h0 + (tid & 15), H - 1) * 4u;
+  __builtin_amdgcn_sched_barrier(0);
+  const float wold = ld_ub(p.oW1, wo);     // fused: old weight; gradient mode: a valid location, ignored
+  const float b1old = ld_ub(p.ob1, b1o);
+  // the step counter travels with the other old values instead of a dependent load + store at the
+  // very end of the statistics block (which finishes last); any valid address when there is none
+  const float gs_old = *(p.global_step ? p.global_step : p.lr);
+  __builtin_amdgcn_sched_barrier(0);
+
+  DTF_STAMP2(1);
+  // ---- phase 1: stage logits/labels, then softmax-xent ----------------------------------------
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * kBwdThreads;       // all 128 rows are staged: rows >= M as zeros
+    const bool ok = (e >> 4) < M && (e & 15) < C;
+    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
+    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
+  }
+  // every thread stages its W2 load (rows 16-31 repeat rows 0-15 and are not read)
+  w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + ((tid >> 4) & 15) < H && (tid & 15) < C) ? w2reg : 0.f;
+  if (tid < 16) {
+    b2s[tid] = tid < C ? b2raw : 0.f;
+    db2s[tid] = 0.f;
+  }
+  __syncthreads();
+  const float inv_batch = 1.0f / (float)M;
+  {
+    const int row = tid >> 2, part = tid & 3;      // 128 rows: every row of dz3s is written
+    const bool row_ok = row < M;
+    float z[4], y[4], ex[4];
+    float mx = -INFINITY, ysum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * part + i;
+      z[i] = zs[row * kLdw + c] + b2s[c];
+      y[i] = ys[row * kLdw + c];
+      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
+      ysum += y[i];
+    }
+    mx = fmaxf(mx, dpp_f<kXor1>(mx));
+    mx = fmaxf(mx, dpp_f<kXor2>(mx));
+    ysum += dpp_f<kXor1>(ysum);
+    ysum += dpp_f<kXor2>(ysum);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
+      se += ex[i];
+    }
+    se += dpp_f<kXor1>(se);
+    se += dpp_f<kXor2>(se);
+    const float inv = fast_rcp(se) * ysum;
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
+    *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
+    if (stats_block) {   // block-uniform
+      const float lse = mx + fast_log(se);
+      float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
+      int az = 0, ay = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * part + i;
+        if (c < C) {
+          rloss -= y[i] * (z[i] - lse);
+          if (z[i] > bz) { bz = z[i]; az = c; }
+          if (y[i] > by) { by = y[i]; ay = c; }
+        }
+      }
+      rloss += dpp_f<kXor1>(rloss);
+      rloss += dpp_f<kXor2>(rloss);
+      argmax_step<kXor1>(bz, az);
+      argmax_step<kXor2>(bz, az);
+      argmax_step<kXor1>(by, ay);
+      argmax_step<kXor2>(by, ay);
+      if (part == 0) {
+        rowstat[row] = row_ok ? rloss : 0.f;
+        rowstat[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  DTF_STAMP2(2);
+  const float gs = p.grad_scale;
+
+  if (!stats_block) {
+    // ---- phase 2: rows beyond the batch need no mask (their dz3 rows are zero) ----------------
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float db1part = 0.f;
+    if (is_main) {
+      float w2row[4 * CQ];
+#pragma unroll
+      for (int c = 0; c < 4 * CQ; ++c) w2row[c] = w2t[i16 * kLdw + c];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int m = 4 * (wave + j * kBwdWaves) + q;              // <= 127
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + m * kLdz);
+        float part[CQ];
+#pragma unroll
+        for (int qd = 0; qd < CQ; ++qd) {
+          const f32x4 d = d4[qd];
+          part[qd] = d[0] * w2row[4 * qd] + d[1] * w2row[4 * qd + 1] + d[2] * w2row[4 * qd + 2] +
+                     d[3] * w2row[4 * qd + 3];
+        }
+        float da = part[0];
+#pragma unroll
+        for (int qd = 1; qd < CQ; ++qd) da += part[qd];
+        const float dz2 = da * dtf_act_bwd(areg[j], p.act);
+        db1part += dz2;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[j], dz2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[j], dz2, acc1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int m = 4 * (wave + j * kBwdWaves) + q;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j], dz3s[m * kLdz + i16], acc0, 0, 0, 0);
+      }
+    }
+    DTF_STAMP2(3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      red[(wave * 8 + g) * 64 + lane] = acc0[g];
+      red[(wave * 8 + 4 + g) * 64 + lane] = acc1[g];
+    }
+    __syncthreads();
+    DTF_STAMP2(4);
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 8 + 4 * o_sub + o_reg) * 64 + o_ln];
+      if (is_main) {
+        const int orow = k0 + o_trow, ocol = h0 + o_tcol;
+        if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold - lr * s : gs * s;
+      } else if (o_sub == 0) {
+        const int h = h0 + o_trow;
+        if (h < H && o_tcol < C) p.oW2[h * C + o_tcol] = p.fused ? w2t[o_trow * kLdw + o_tcol] - lr * s : gs * s;
+      }
+    }
+    DTF_STAMP2(5);
+    // db1: the workgroups of k-tile 0 see every batch row of their 16 columns
+    if (is_main && tk == 0) {
+      __syncthreads();   // red is reused
+      db1part += __shfl_xor(db1part, 16);
+      db1part += __shfl_xor(db1part, 32);
+      if (lane < 16) red[wave * 16 + lane] = db1part;
+      __syncthreads();
+      if (tid < 16 && h0 + tid < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
+        p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
+      }
+    }
+    DTF_STAMP2(6);
+  } else {
+    DTF_STAMP2(3);
+    {
+      // db2[c] = sum over rows of dz3: thread (part = tid >> 4, c = tid & 15) sums rows part, part + 32, ...;
+      // the four parts of a wave are folded with two shuffles, the eight waves through LDS
+      const int c = tid & 15, part = tid >> 4;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += dz3s[(part + 32 * k) * kLdz + c];     // rows >= M are zero
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red[wave * 16 + lane] = s;
+    }
+    {   // per-row loss / correct flags: 128 rows over the 512 threads' first 128, folded per wave
+      float l = tid < 128 ? rowstat[tid] : 0.f;
+      float k = tid < 128 ? rowstat[128 + tid] : 0.f;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        l += __shfl_xor(l, m);
+        k += __shfl_xor(k, m);
+      }
+      if (lane == 0 && wave < 2) {
+        red[128 + wave] = l;
+        red[130 + wave] = k;
+      }
+    }
+    __syncthreads();
+    DTF_STAMP2(4);
+    if (tid < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
+      p.ob2[tid] = p.fused ? b2s[tid] - lr * s : gs * s;
+    }
+    if (tid == 0) {
+      if (p.loss_hist) p.loss_hist[p.hist_slot] = (red[128] + red[129]) * inv_batch;
+      if (p.acc_hist) p.acc_hist[p.hist_slot] = (red[130] + red[131]) * inv_batch;
+      DTF_STAMP2(5);
+      if (p.fused && p.global_step) *p.global_step = gs_old + 1.0f;
+      DTF_STAMP2(6);
+    }
+  }
+  DTF_STAMP2(7);
+  DTF_BLOCK_STAMP(p.bs, 1);
+}
+
+bool g_bwd_tile16 = true;
 bool g_fwd_tile8 = true;
 long long* g_stamps2 = nullptr;
 int g_stamp_block = 1;
@@ -917,22 +1209,32 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.M = B; p.K = K; p.H = H; p.C = C; p.R = R; p.act = d->act; p.fused = fused ? 1 : 0;
   p.stamps = g_stamps2;
   p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 256 : nullptr};
-  const int tiles_k = (K + 31) / 32, tiles_h = (H + 31) / 32;
-  const int duty_blocks = tiles_h + 1;
+  const int tiles_k = (K + 31) / 32, cq = (C + 3) / 4;
+  const int tiles_h = g_bwd_tile16 ? (H + 15) / 16 : (H + 31) / 32;
   // linear ids: dW1 tiles, then dW2 tiles, then the statistics block (negative: counted from it backwards)
-  p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + duty_blocks + g_stamp_block;
-  const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves, cq = (C + 3) / 4;
+  p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + tiles_h + 1 + g_stamp_block;
   const dim3 grid(tiles_h, tiles_k + 2), block(kBwdThreads);
-  if (nj <= 7 && cq <= 3) {          // the reference shape: batch 100, 10 classes
-    hipLaunchKernelGGL((bwd_all_kernel<7, 3>), grid, block, 0, stream, p);
+  if (g_bwd_tile16) {
+    if (cq <= 3) {
+      hipLaunchKernelGGL((bwd_tile16_kernel<4, 3>), grid, block, 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((bwd_tile16_kernel<4, 4>), grid, block, 0, stream, p);
+    }
   } else {
-    hipLaunchKernelGGL((bwd_all_kernel<8, 4>), grid, block, 0, stream, p);
+    const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves;
+    if (nj <= 7 && cq <= 3) {          // the reference shape: batch 100, 10 classes
+      hipLaunchKernelGGL((bwd_all_kernel<7, 3>), grid, block, 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((bwd_all_kernel<8, 4>), grid, block, 0, stream, p);
+    }
   }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
 // Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.
 extern "C" void dtf_debug_set_fwd_tile8(int on) { g_fwd_tile8 = on != 0; }
+// Same for the backward launch: 32x16 tiles of dW1 (default) or 32x32 tiles.
+extern "C" void dtf_debug_set_bwd_tile16(int on) { g_bwd_tile16 = on != 0; }
 
 // Profiling hook: device buffer of >= 32 int64 receiving {wall_clock64, clock64}
 // at the phase boundaries of the LAST workgroup of bwd_all; null disables.
