@@ -373,6 +373,17 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
     const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
     float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
     int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
+  // The last grid row holds no tile: its first workgroup refreshes the shadow copy of W2/b2 and
+  // clears the other logit accumulator, beside the tiles instead of at the tail of one of them.
+  if (blockIdx.y == gridDim.y - 1) {
+    if (blockIdx.x == 0) {
+      const int hcw = H * C;
+      if (shadow_dst)
+        for (int e = threadIdx.x; e < hcw + C; e += kFwdWaves * 64) shadow_dst[e] = e < hcw ? W2[e] : b2[e - hcw];
+      for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
+    }
+    return;
+  }
   DTF_BLOCK_STAMP(bs, 0);
   __shared__ float red[kFwdWaves][4][64];
   __shared__ float psum[2][64];
@@ -404,9 +415,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
   const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;           // threads < 128: W2 tile element
   const bool w2_ok = w_h < 8 && n0 + w_h < H && w_c < C;
   const unsigned w2o = umin_(__umul24(n0 + (w_h & 7), C) + w_c, (unsigned)H * C - 1) * 4u;
-  const unsigned se = threadIdx.x, hc = (unsigned)H * C;
-  const bool s_in_w2 = se < hc;
-  const unsigned sow = umin_(se, hc - 1) * 4u, sob = umin_(se - hc, C - 1) * 4u;   // se < hc wraps: clamped
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- loads, back to back ------------------------------------------------------------------
@@ -421,8 +429,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
   __builtin_amdgcn_sched_barrier(0);
   const float bias = ld_ub(b, bo);
   const float w2raw = ld_ub(W2, w2o);
-  const float sh_w = ld_ub(W2, sow);
-  const float sh_b = ld_ub(b2, sob);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- contraction ------------------------------------------------------------------------------
@@ -472,10 +478,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
       for (int h = 0; h < 8; ++h) z += a2t[r][h] * w2t[h][c];
       atomicAdd(&zacc[(m0 + r) * 16 + c], z);
     }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (shadow_dst && se < hc + C) shadow_dst[se] = s_in_w2 ? sh_w : sh_b;
-    for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
   }
   DTF_BLOCK_STAMP(bs, 1);
 }
@@ -1159,9 +1161,9 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   dim3(tiles_n, tiles_m), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
   const int ns8 = ((K + 15) / 16 + 31) / 32;   // slots of the 8x8 tiling: 32 macro-steps per slot
-  const bool tile8 = g_fwd_tile8 && (K & 3) == 0 && K >= 16 && ns8 <= 4 && H * C + C <= kFwdWaves * 64;
+  const bool tile8 = g_fwd_tile8 && (K & 3) == 0 && K >= 16 && ns8 <= 4;
 #define DTF_FWD8_ARGS                                                                                 \
-  dim3((H + 7) / 8, (B + 7) / 8), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
+  dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
   if (tile8 && ns8 == 2) {
     hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_FWD8_ARGS);
