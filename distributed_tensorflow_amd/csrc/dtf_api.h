@@ -43,6 +43,20 @@ typedef struct DtfMlpDesc {
   float* zws;                 // [2][2048] zero-initialised logit ping-pong accumulators
 } DtfMlpDesc;
 
+// Extra state of the one-launch-per-step ("pipelined") chunk, see dtf_mlp_chunk_pipelined.
+typedef struct DtfPipeDesc {
+  float* tW1;                 // twin parameter set (same shapes as W1, b1, W2, b2): the steps of a
+  float* tb1;                 //   chunk alternate between the caller's tensors and these
+  float* tW2;
+  float* tb2;
+  float* a2b;                 // second [B, H] activation buffer (the first one is DtfMlpDesc.z2)
+  float* zws3;                // [3][2048] logit accumulators
+  const float* gram;          // [batches_per_epoch - 1][B][gram_ld]: gram[j][m][i] = 1 + x_{j+1}[m] . x_j[i],
+                              //   zero for i >= B
+  int32_t gram_ld;            // multiple of 16, B <= gram_ld <= 128
+  int32_t reserved;
+} DtfPipeDesc;
+
 // `batch_index` = mini-batch of the resident set (added to *cursor when a
 // device cursor is used).  `parity` must alternate 0,1,0,1,... over consecutive
 // steps of one descriptor (it selects the logit accumulator half).
@@ -50,6 +64,12 @@ typedef struct DtfMlpDesc {
 int dtf_mlp_step_fused(const DtfMlpDesc* d, int batch_index, int parity, void* stream);
 // fwd + loss + bwd writing gradients (scaled by grad_scale) to g*; no update.
 int dtf_mlp_step_grad(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, void* stream);
+// n fused steps on mini-batches first_batch .. first_batch + n - 1 of the current epoch with ONE
+// launch per step: step t's backward and step t+1's forward share a launch (the forward is taken
+// from the pre-update parameters plus a rank-B correction through the Gram blocks of consecutive
+// batches).  Same results as n calls of dtf_mlp_step_fused up to fp32 rounding.
+int dtf_mlp_chunk_pipelined_supported(int B, int K, int H, int C);
+int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n, void* stream);
 // cursor += n  (one thread).
 int dtf_advance_cursor(int32_t* cursor, int n, void* stream);
 

@@ -496,8 +496,12 @@ struct BwdParams {
   long batch_index;
   const float* W2r;       // W2 to READ (shadow in fused mode, live otherwise) [H,C]
   const float* b2r;       // b2 to READ [C]
-  float* oW1;             // fused: live W1; grad: gW1
-  float* ob1;             // fused: live b1; grad: gb1
+  float* oW1;             // fused: W1 to WRITE; grad: gW1
+  float* ob1;             // fused: b1 to WRITE; grad: gb1
+  const float* rW1;       // fused: W1 holding the OLD values (== oW1 for an in-place update); grad: gW1
+  const float* rb1;       // same for b1
+  float* zclear;          // logit accumulator the statistics block zeroes for a later step (may be null)
+  int zclear_n;
   float* oW2;             // fused: live W2; grad: gW2
   float* ob2;             // fused: live b2; grad: gb2
   const float* lr;
@@ -512,6 +516,17 @@ struct BwdParams {
   BlockStamps bs;
 };
 
+#define DTF_BLOCK_STAMP_AT(bs, lin, which)                                                \
+  do {                                                                                    \
+    if ((bs).buf && threadIdx.x == 0) (bs).buf[2 * (lin) + (which)] = (long long)wall_clock64(); \
+  } while (0)
+#define DTF_STAMP2_AT(lin, i)                                                  \
+  do {                                                                         \
+    if (p.stamps && threadIdx.x == 0 && (lin) == p.stamp_block) {              \
+      p.stamps[2 * (i)] = (long long)wall_clock64();                           \
+      p.stamps[2 * (i) + 1] = (long long)clock64();                            \
+    }                                                                          \
+  } while (0)
 #define DTF_STAMP2(i)                                                          \
   do {                                                                         \
     if (p.stamps && threadIdx.x == 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) == p.stamp_block) { \
@@ -845,10 +860,12 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
 // The a2 operand has the same lane mapping in both roles, so — as in bwd_all_kernel — every
 // block executes one straight-line sequence of loads.  dz2 is formed once per (row, column)
 // and feeds both MFMAs: half the dot products of the 32x32 tiling.
+constexpr int kBwd16Smem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 256 + 64;
+
+// (bx, by) = position in the backward part of the grid, `lin` = linear id for the profiling stamps.
 template <int NS, int CQ>
-__global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
+__device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4, "operand slots");
-  __shared__ __attribute__((aligned(16))) float smem[2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 256 + 64];
   float* red = smem;                         // [8 waves][8][64] partial tiles (phase 2+)
   float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
   float* ys = smem + 128 * kLdw;             // [128][17] labels    (phase 1, aliases red)
@@ -865,14 +882,14 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   // 2-D grid: x = h tile (16 columns); y < tiles_k: dW1 tile row y (32 rows); y == tiles_k: dW2
   // tile x; y == tiles_k + 1: the statistics block (x == 0; its tile loads are unused).
   const int tiles_k = (K + 31) >> 5;
-  const bool is_main = (int)blockIdx.y < tiles_k;
-  const bool stats_block = (int)blockIdx.y == tiles_k + 1;
-  if (stats_block && blockIdx.x != 0) return;
-  const int th = blockIdx.x, tk = is_main ? (int)blockIdx.y : 0;
+  const bool is_main = by < tiles_k;
+  const bool stats_block = by == tiles_k + 1;
+  if (stats_block && bx != 0) return;
+  const int th = bx, tk = is_main ? by : 0;
   const int k0 = tk * 32, h0 = th * 16;
 
-  DTF_BLOCK_STAMP(p.bs, 0);
-  DTF_STAMP2(0);
+  DTF_BLOCK_STAMP_AT(p.bs, lin, 0);
+  DTF_STAMP2_AT(lin, 0);
   // ---- phase 0: three pinned groups of loads, offsets of a group computed just before it ------
   const float* __restrict__ X = p.xbase + p.batch_index * (long)M * (long)K;
   const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;
@@ -927,14 +944,14 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   const unsigned wo = umin_(__umul24(k0 + o_trow, H) + h0 + o_tcol, (unsigned)K * H - 1) * 4u;
   const unsigned b1o = umin_(h0 + (tid & 15), H - 1) * 4u;
   __builtin_amdgcn_sched_barrier(0);
-  const float wold = ld_ub(p.oW1, wo);     // fused: old weight; gradient mode: a valid location, ignored
-  const float b1old = ld_ub(p.ob1, b1o);
+  const float wold = ld_ub(p.rW1, wo);     // fused: old weight; gradient mode: a valid location, ignored
+  const float b1old = ld_ub(p.rb1, b1o);
   // the step counter travels with the other old values instead of a dependent load + store at the
   // very end of the statistics block (which finishes last); any valid address when there is none
   const float gs_old = *(p.global_step ? p.global_step : p.lr);
   __builtin_amdgcn_sched_barrier(0);
 
-  DTF_STAMP2(1);
+  DTF_STAMP2_AT(lin, 1);
   // ---- phase 1: stage logits/labels, then softmax-xent ----------------------------------------
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -1008,7 +1025,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
     }
   }
   __syncthreads();
-  DTF_STAMP2(2);
+  DTF_STAMP2_AT(lin, 2);
   const float gs = p.grad_scale;
 
   if (!stats_block) {
@@ -1045,14 +1062,14 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[j], dz3s[m * kLdz + i16], acc0, 0, 0, 0);
       }
     }
-    DTF_STAMP2(3);
+    DTF_STAMP2_AT(lin, 3);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       red[(wave * 8 + g) * 64 + lane] = acc0[g];
       red[(wave * 8 + 4 + g) * 64 + lane] = acc1[g];
     }
     __syncthreads();
-    DTF_STAMP2(4);
+    DTF_STAMP2_AT(lin, 4);
     {
       float s = 0.f;
 #pragma unroll
@@ -1065,7 +1082,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
         if (h < H && o_tcol < C) p.oW2[h * C + o_tcol] = p.fused ? w2t[o_trow * kLdw + o_tcol] - lr * s : gs * s;
       }
     }
-    DTF_STAMP2(5);
+    DTF_STAMP2_AT(lin, 5);
     // db1: the workgroups of k-tile 0 see every batch row of their 16 columns
     if (is_main && tk == 0) {
       __syncthreads();   // red is reused
@@ -1080,9 +1097,9 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
         p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
       }
     }
-    DTF_STAMP2(6);
+    DTF_STAMP2_AT(lin, 6);
   } else {
-    DTF_STAMP2(3);
+    DTF_STAMP2_AT(lin, 3);
     {
       // db2[c] = sum over rows of dz3: thread (part = tid >> 4, c = tid & 15) sums rows part, part + 32, ...;
       // the four parts of a wave are folded with two shuffles, the eight waves through LDS
@@ -1108,23 +1125,314 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
       }
     }
     __syncthreads();
-    DTF_STAMP2(4);
+    DTF_STAMP2_AT(lin, 4);
     if (tid < C) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
       p.ob2[tid] = p.fused ? b2s[tid] - lr * s : gs * s;
     }
+    if (p.zclear)
+      for (int e = tid; e < p.zclear_n; e += kBwdThreads) p.zclear[e] = 0.f;
     if (tid == 0) {
       if (p.loss_hist) p.loss_hist[p.hist_slot] = (red[128] + red[129]) * inv_batch;
       if (p.acc_hist) p.acc_hist[p.hist_slot] = (red[130] + red[131]) * inv_batch;
-      DTF_STAMP2(5);
+      DTF_STAMP2_AT(lin, 5);
       if (p.fused && p.global_step) *p.global_step = gs_old + 1.0f;
-      DTF_STAMP2(6);
+      DTF_STAMP2_AT(lin, 6);
     }
   }
-  DTF_STAMP2(7);
-  DTF_BLOCK_STAMP(p.bs, 1);
+  DTF_STAMP2_AT(lin, 7);
+  DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
+}
+
+template <int NS, int CQ>
+__global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[kBwd16Smem];
+  bwd_tile16_body<NS, CQ>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// One launch per training step ("pipelined" chunk).
+//
+// Step t's backward and step t+1's forward are separated by a grid-wide dependency (every
+// tile of W1 is updated by a different workgroup), which as two launches costs two kernel
+// boundaries of ~2 us on a step whose kernel bodies take ~3 us each.  The forward of step t+1
+// can however be written in terms of the parameters BEFORE the update of step t:
+//
+//   z2'[m][n] = sum_k x'[m][k] W1new[k][n] + b1new[n]
+//             = sum_k x'[m][k] W1old[k][n] + b1old[n] - lr * sum_j (1 + x'[m].x[j]) dz2[j][n]
+//
+// (x: batch t, x': batch t+1, dz2: step t's hidden-layer gradient, W1new = W1old - lr x^T dz2,
+// b1new = b1old - lr sum_j dz2[j]).  The Gram block G1[m][j] = 1 + x'[m].x[j] depends on the
+// data only and is computed for every pair of consecutive batches when the epoch is shuffled
+// (one batched GEMM); dz2 restricted to the columns of a tile is a cheap function of step t's
+// activations and logits.  So a forward workgroup of step t+1 needs nothing that another
+// workgroup of the same launch produces, and ONE launch holds
+//     [forward tiles of step t+1] ++ [dW1 tiles, dW2 tiles, statistics block of step t].
+// Parameters are double-buffered per step (read set / write set) because the forward tiles read
+// the old values while the backward tiles store the new ones; the logit accumulator is triple
+// buffered (read, accumulate, clear).  The correction rides in the same MFMA accumulators as the
+// main product: it is one more contraction slot whose A operand is -lr * G1 and whose B operand
+// is dz2 (from LDS).  W2new rows of the tile (for the logit partials) are rebuilt locally too.
+struct PipeParams {
+  BwdParams b;             // backward part (step t); also carries the shapes and common inputs
+  const float* W1r;        // forward part: parameters before step t's update
+  const float* b1r;
+  long next_index;         // batch t+1
+  const float* gram;       // G1 of the pair (t, t+1): [M][gram_ld], zero beyond column M
+  int gram_ld;             // multiple of 16
+  float* a2_next;          // [M][H] activations of step t+1
+  float* zacc_next;        // logit accumulator of step t+1 (zero on entry)
+  int fwd_rows;            // grid rows of forward tiles (0: no forward part in this launch)
+  int tiles_n8;
+  int tiles_h16;
+};
+
+constexpr int kPipeFwdSlots = 4;      // 8 waves x 4 slots x 2 ranges = 64 macro-steps: K <= 1024
+constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 9 + 4 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
+
+template <int CQ>
+__device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem, int tn, int tm, int lin) {
+  const BwdParams& p = pp.b;
+  float* red = smem;                         // [8 waves][4][64] (after the contraction)
+  float* zs = smem;                          // [128][17] logits of step t (phase 1, aliases red)
+  float* ys = smem + 128 * kLdw;             // [128][17] labels of step t
+  float* dz3s = smem + 2 * 128 * kLdw;       // [128][kLdz]
+  float* w2t = dz3s + 128 * kLdz;            // [32][17]: rows 0-7 = old W2 rows of the tile's columns
+  float* dz2s = w2t + 32 * kLdw;             // [128][9] dz2 of step t, tile columns
+  float* a2s = dz2s + 128 * 9;               // [128][9] a2 of step t, tile columns
+  float* w2n = a2s + 128 * 9;                // [4][8][16] partial sums of a2^T dz3
+  float* w2new = w2n + 4 * 8 * 16;           // [8][17] new W2 rows of the tile's columns
+  float* psum = w2new + 8 * kLdw;            // [2][64]
+  float* a2t = psum + 128;                   // [8][9] new activations
+  float* b2s = a2t + 80;                     // [16]
+
+  const int H = p.H, C = p.C, M = p.M, K = p.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int r8 = i16 & 7, g = i16 >> 3;
+  const int m0 = tm * 8, n0 = tn * 8;
+  DTF_BLOCK_STAMP_AT(p.bs, lin, 0);
+  const float* __restrict__ Xn = p.xbase + pp.next_index * (long)M * (long)K;     // batch t+1
+  const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;      // labels of batch t
+  const float lr = *p.lr;
+  const int row = m0 + r8, col = n0 + r8;
+  const bool col_ok = col < H;
+  const unsigned row_c = row < M ? row : M - 1, col_c = col_ok ? col : H - 1;
+
+  // ---- group 1: what the softmax and dz2 of step t need ------------------------------------------
+  const unsigned y_max = (unsigned)M * C - 1;
+  unsigned yo[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned e = tid + u * kBwdThreads;
+    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
+  }
+  const unsigned b2o = umin_(tid, C - 1) * 4u;
+  const unsigned w2o = umin_(__umul24(umin_(n0 + ((tid >> 4) & 7), H - 1), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
+  unsigned aco[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const unsigned e = tid + u * kBwdThreads;              // element (j = e >> 3, c = e & 7) of the a2 column tile
+    aco[u] = (__umul24(umin_(e >> 3, M - 1), H) + umin_(n0 + (e & 7), H - 1)) * 4u;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float zreg[4], yreg[4], a2c[2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
+    yreg[u] = ld_ub(Y, yo[u]);
+  }
+  const float b2raw = ld_ub(p.b2r, b2o);
+  const float w2reg = ld_ub(p.W2r, w2o);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) a2c[u] = ld_ub(p.a2, aco[u]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- group 2: correction operand (G1 rows of the tile) and the bias ---------------------------------
+  const unsigned jb = (2u * wave + g) * 16u + q * 4u;               // batch rows jb..jb+3 of step t
+  const bool jok = jb < (unsigned)pp.gram_ld;
+  const unsigned go = (__umul24(row_c, pp.gram_ld) + (jok ? jb : 0u)) * 4u;
+  const unsigned bo = umin_(col, H - 1) * 4u;
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pp.gram) + go);
+  const float bias = ld_ub(pp.b1r, bo);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- group 3: the main operands (x' rows, old W1 columns): needed last, issued last ---------------------
+  unsigned xo[kPipeFwdSlots], wo[kPipeFwdSlots][4];
+  bool kok[kPipeFwdSlots];
+#pragma unroll
+  for (int j = 0; j < kPipeFwdSlots; ++j) {
+    const unsigned kb = (2u * (wave + j * kBwdWaves) + g) * 16u + q * 4u;
+    kok[j] = kb < (unsigned)K;
+    const unsigned kbc = kok[j] ? kb : K - 4;
+    xo[j] = (__umul24(row_c, K) + kbc) * 4u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wo[j][s] = (__umul24(kbc + s, H) + col_c) * 4u;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 a[kPipeFwdSlots];
+  float bv[kPipeFwdSlots][4];
+#pragma unroll
+  for (int j = 0; j < kPipeFwdSlots; ++j) {
+    a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Xn) + xo[j]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(pp.W1r, wo[j][s]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- phase 1: stage, softmax of step t -> dz3s -----------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * kBwdThreads;
+    const bool ok = (e >> 4) < M && (e & 15) < C;
+    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
+    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
+  }
+  w2t[(tid >> 4) * kLdw + (tid & 15)] = (n0 + ((tid >> 4) & 7) < H && (tid & 15) < C) ? w2reg : 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kBwdThreads;
+    a2s[(e >> 3) * 9 + (e & 7)] = ((e >> 3) < M && n0 + (e & 7) < H) ? a2c[u] : 0.f;
+  }
+  if (tid < 16) b2s[tid] = tid < C ? b2raw : 0.f;
+  __syncthreads();
+  const float inv_batch = 1.0f / (float)M;
+  {
+    const int srow = tid >> 2, part = tid & 3;
+    const bool row_ok = srow < M;
+    float z[4], y[4], ex[4];
+    float mx = -INFINITY, ysum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * part + i;
+      z[i] = zs[srow * kLdw + c] + b2s[c];
+      y[i] = ys[srow * kLdw + c];
+      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
+      ysum += y[i];
+    }
+    mx = fmaxf(mx, dpp_f<kXor1>(mx));
+    mx = fmaxf(mx, dpp_f<kXor2>(mx));
+    ysum += dpp_f<kXor1>(ysum);
+    ysum += dpp_f<kXor2>(ysum);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
+      se += ex[i];
+    }
+    se += dpp_f<kXor1>(se);
+    se += dpp_f<kXor2>(se);
+    const float inv = fast_rcp(se) * ysum;
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
+    *reinterpret_cast<f32x4*>(dz3s + srow * kLdz + 4 * part) = out;
+  }
+  __syncthreads();
+
+  // ---- phase 2: dz2 of step t for the tile's columns; partial sums of a2^T dz3 (-> new W2 rows) ---------------
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * kBwdThreads;
+    const int j = e >> 3, c = e & 7;
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + j * kLdz);
+    float da = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < CQ; ++qd) {
+      const f32x4 d = d4[qd];
+      da += d[0] * w2t[c * kLdw + 4 * qd] + d[1] * w2t[c * kLdw + 4 * qd + 1] + d[2] * w2t[c * kLdw + 4 * qd + 2] +
+            d[3] * w2t[c * kLdw + 4 * qd + 3];
+    }
+    dz2s[j * 9 + c] = da * dtf_act_bwd(a2s[j * 9 + c], p.act);      // rows >= M: dz3 == 0
+  }
+  {
+    const int c = tid & 7, cls = (tid >> 3) & 15, part = tid >> 7;
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = part; j < 128; j += 4) s += a2s[j * 9 + c] * dz3s[j * kLdz + cls];
+    w2n[(part * 8 + c) * 16 + cls] = s;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int c = tid >> 4, cls = tid & 15;
+    const float s = w2n[c * 16 + cls] + w2n[(8 + c) * 16 + cls] + w2n[(16 + c) * 16 + cls] + w2n[(24 + c) * 16 + cls];
+    w2new[c * kLdw + cls] = w2t[c * kLdw + cls] - lr * s;            // zero beyond H / C stays zero
+  }
+
+  // ---- contraction: correction slot first (its operands are here), then the main slots -------------------------
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const bool ok = col_ok && jok;
+    const unsigned jc = jok ? jb : 0u;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[0], ok ? dz2s[(jc + 0) * 9 + r8] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[1], ok ? dz2s[(jc + 1) * 9 + r8] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[2], ok ? dz2s[(jc + 2) * 9 + r8] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[3], ok ? dz2s[(jc + 3) * 9 + r8] : 0.f, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < kPipeFwdSlots; ++j) {
+    const bool ok = col_ok && kok[j];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
+  }
+  const f32x4 acc = acc0 + acc1;
+  const float badd = (wave == 0 && g == 0) ? bias : 0.f;
+  // (zs / ys, which red aliases, were last read before the two barriers above)
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) red[(wave * 4 + rg) * 64 + lane] = acc[rg] + badd;
+  __syncthreads();
+  if (tid < 128) {
+    const int blk = tid >> 6, r = (tid >> 3) & 7, c = tid & 7;
+    const int drow = 8 * blk + r, dcol = 8 * blk + c;
+    const int rg = drow & 3, ln = ((drow >> 2) << 4) | dcol;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + rg) * 64 + ln];
+    psum[blk * 64 + (tid & 63)] = s;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int r = tid >> 3, c = tid & 7;
+    const int orow = m0 + r, ocol = n0 + c;
+    float av = 0.f;
+    if (orow < M && ocol < H) {
+      av = fast_act(psum[tid] + psum[64 + tid], p.act);
+      pp.a2_next[(long)orow * H + ocol] = av;
+    }
+    a2t[r * 9 + c] = av;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int r = tid >> 4, cls = tid & 15;
+    if (m0 + r < M && cls < C) {
+      float z = 0.f;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) z += a2t[r * 9 + h] * w2new[h * kLdw + cls];
+      atomicAdd(&pp.zacc_next[(m0 + r) * 16 + cls], z);
+    }
+  }
+  DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
+}
+
+template <int CQ>
+__global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp) {
+  constexpr int kSmem = kPipeFwdSmem > kBwd16Smem ? kPipeFwdSmem : kBwd16Smem;
+  __shared__ __attribute__((aligned(16))) float smem[kSmem];
+  const int by = blockIdx.y, bx = blockIdx.x;
+  if (by < pp.fwd_rows) {                       // forward tile of step t+1
+    if (bx >= pp.tiles_n8) return;
+    pipe_fwd_body<CQ>(pp, smem, bx, by, 512 + by * pp.tiles_n8 + bx);
+    return;
+  }
+  if (bx >= pp.tiles_h16) return;               // backward part of step t
+  const int byb = by - pp.fwd_rows;
+  bwd_tile16_body<4, CQ>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
 }
 
 bool g_bwd_tile16 = true;
@@ -1198,6 +1506,10 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.ob1 = fused ? d->b1 : d->gb1;
   p.oW2 = fused ? d->W2 : d->gW2;
   p.ob2 = fused ? d->b2 : d->gb2;
+  p.rW1 = p.oW1;
+  p.rb1 = p.ob1;
+  p.zclear = nullptr;
+  p.zclear_n = 0;
   p.lr = d->lr;
   p.grad_scale = grad_scale;
   p.loss_hist = d->loss_hist;
@@ -1246,3 +1558,97 @@ extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block
 // Profiling hook: device buffer of >= 2*(256 + backward grid) int64 receiving per-block
 // {start, end} wall-clock stamps of the next two-launch steps; null disables.
 extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }
+
+// n consecutive fused steps starting at mini-batch `first_batch`, ONE launch per step (plus one
+// stand-alone forward for the first step): see step_pipe_kernel.  The chunk must stay inside one
+// epoch of the resident set, whose Gram blocks q->gram describe.
+extern "C" int dtf_mlp_chunk_pipelined_supported(int B, int K, int H, int C) {
+  return dtf_step2_supported(B, K, H, C) && (K & 3) == 0 && K >= 16 && K <= 1024 ? 1 : 0;
+}
+
+extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n,
+                                       void* stream_) {
+  if (!d || !q) return DTF_ERR_NULL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
+  if (!dtf_mlp_chunk_pipelined_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
+  if (!d->x || !d->y || !d->W1 || !d->b1 || !d->W2 || !d->b2 || !d->z2 || !d->lr) return DTF_ERR_NULL;
+  if (!q->tW1 || !q->tb1 || !q->tW2 || !q->tb2 || !q->a2b || !q->zws3 || !q->gram) return DTF_ERR_NULL;
+  if (n < 1 || first_batch < 0 || first_batch + n > d->batches_per_epoch) return DTF_ERR_SHAPE;
+  if (q->gram_ld < B || (q->gram_ld & 15) || q->gram_ld > 128) return DTF_ERR_SHAPE;
+  const int R = ((B + 15) / 16) * 16;
+  const int tiles_m8 = (B + 7) / 8, tiles_n8 = (H + 7) / 8, tiles_h16 = (H + 15) / 16, tiles_k = (K + 31) / 32;
+  const int cq = (C + 3) / 4;
+  struct Set { float *W1, *b1, *W2, *b2; };
+  const Set canon{d->W1, d->b1, d->W2, d->b2}, twin{q->tW1, q->tb1, q->tW2, q->tb2};
+  float* a2buf[2] = {d->z2, q->a2b};
+  float* zw[3] = {q->zws3, q->zws3 + 2048, q->zws3 + 4096};
+  if (hipMemsetAsync(q->zws3, 0, sizeof(float) * 3 * 2048, stream) != hipSuccess) return DTF_ERR_LAUNCH;
+  // The last step has to leave the parameters in the caller's tensors, so an odd chunk starts
+  // from the twin set (a copy of the same values).
+  const bool start_twin = (n & 1) != 0;
+  if (start_twin) {
+    if (hipMemcpyAsync(twin.W1, canon.W1, sizeof(float) * K * H, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(twin.b1, canon.b1, sizeof(float) * H, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(twin.W2, canon.W2, sizeof(float) * H * C, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(twin.b2, canon.b2, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return DTF_ERR_LAUNCH;
+  }
+  // forward of the first step, from the caller's parameters
+  {
+    const int ns8 = ((K + 15) / 16 + 31) / 32;
+    const dim3 grid(tiles_n8, tiles_m8 + 1), block(kFwdWaves * 64);
+#define DTF_F0_ARGS grid, block, 0, stream, d->x, (long)first_batch, d->W1, d->b1, d->W2, a2buf[0], zw[0], zw[1], \
+                    R * 16, B, K, H, C, d->act, (float*)nullptr, d->b2, BlockStamps{nullptr}
+    if (ns8 == 1) {
+      hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_F0_ARGS);
+    } else {
+      hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_F0_ARGS);
+    }
+#undef DTF_F0_ARGS
+  }
+  Set cur = start_twin ? twin : canon;
+  for (int i = 0; i < n; ++i) {
+    const Set nxt = (cur.W1 == canon.W1) ? twin : canon;
+    const long bi = first_batch + i;
+    PipeParams pp;
+    BwdParams& p = pp.b;
+    p.a2 = a2buf[i & 1];
+    p.zacc = zw[i % 3];
+    p.xbase = d->x;
+    p.ybase = d->y;
+    p.batch_index = bi;
+    p.W2r = cur.W2; p.b2r = cur.b2;
+    p.rW1 = cur.W1; p.rb1 = cur.b1;
+    p.oW1 = nxt.W1; p.ob1 = nxt.b1; p.oW2 = nxt.W2; p.ob2 = nxt.b2;
+    p.zclear = zw[(i + 2) % 3];
+    p.zclear_n = R * 16;
+    p.lr = d->lr;
+    p.grad_scale = 1.0f;
+    p.loss_hist = d->hist_cap > 0 ? d->loss_hist : nullptr;
+    p.acc_hist = d->hist_cap > 0 ? d->acc_hist : nullptr;
+    p.hist_slot = d->hist_cap > 0 ? (int)(bi % d->hist_cap) : 0;
+    p.global_step = d->global_step;
+    p.M = B; p.K = K; p.H = H; p.C = C; p.R = R; p.act = d->act; p.fused = 1;
+    p.stamps = g_stamps2;
+    p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h16 + tiles_h16 + 1 + g_stamp_block;
+    p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 256 : nullptr};
+    pp.W1r = cur.W1; pp.b1r = cur.b1;
+    pp.next_index = bi + 1;
+    pp.gram = q->gram + (size_t)bi * B * q->gram_ld;
+    pp.gram_ld = q->gram_ld;
+    pp.a2_next = a2buf[(i + 1) & 1];
+    pp.zacc_next = zw[(i + 1) % 3];
+    pp.fwd_rows = (i < n - 1) ? tiles_m8 : 0;
+    pp.tiles_n8 = tiles_n8;
+    pp.tiles_h16 = tiles_h16;
+    const dim3 grid(tiles_n8 > tiles_h16 ? tiles_n8 : tiles_h16, pp.fwd_rows + tiles_k + 2), block(kBwdThreads);
+    if (cq <= 3) {
+      hipLaunchKernelGGL((step_pipe_kernel<3>), grid, block, 0, stream, pp);
+    } else {
+      hipLaunchKernelGGL((step_pipe_kernel<4>), grid, block, 0, stream, pp);
+    }
+    cur = nxt;
+  }
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}

@@ -207,7 +207,41 @@ class DeviceDataset:
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed)
         self.epoch = -1
+        self.gram = None
         self.shuffle_epoch()
+
+    def enable_pair_gram(self) -> torch.Tensor:
+        """Keep ``gram[j, m, i] = 1 + x_{j+1}[m] . x_j[i]`` for every pair of consecutive mini-batches of the
+        epoch order ([batches_per_epoch - 1, B, ld], ld = B rounded up to 16, zero for i >= B), refreshed in
+        place by every reshuffle with one batched GEMM.  It is what lets a fused training step run as ONE
+        kernel launch (``MLPEngine.bind_gram``): the forward of batch j+1 is computed from the parameters
+        before the update of batch j plus a correction through this block."""
+        if self.gram is None:
+            ld = (self.batch_size + 15) // 16 * 16
+            self.gram = torch.zeros((max(self.batches_per_epoch - 1, 1), self.batch_size, ld),
+                                    dtype=torch.float32, device=self.device)
+            self._refresh_gram()
+        return self.gram
+
+    def _refresh_gram(self):
+        nb, b = self.batches_per_epoch, self.batch_size
+        if self.gram is None or nb < 2:
+            return
+        xb = self.x_epoch[:nb * b].view(nb, b, -1)
+        # fp32 matrix units (no reduced-precision shortcut): the block enters the forward pass exactly
+        torch.baddbmm(self._gram_ones(), xb[1:], xb[:-1].transpose(1, 2), out=self._gram_tmp())
+        self.gram[:, :, :b].copy_(self._gram_tmp_t)
+
+    def _gram_ones(self):
+        if getattr(self, "_gram_ones_t", None) is None:
+            self._gram_ones_t = torch.ones((1, 1, 1), dtype=torch.float32, device=self.device)
+        return self._gram_ones_t
+
+    def _gram_tmp(self):
+        if getattr(self, "_gram_tmp_t", None) is None:
+            nb, b = self.batches_per_epoch, self.batch_size
+            self._gram_tmp_t = torch.empty((nb - 1, b, b), dtype=torch.float32, device=self.device)
+        return self._gram_tmp_t
 
     def shuffle_epoch(self):
         perm = torch.randperm(self.num_examples, generator=self._gen).to(self.device)
@@ -219,3 +253,5 @@ class DeviceDataset:
             torch.index_select(self.x, 0, perm, out=self.x_epoch)
             torch.index_select(self.y, 0, perm, out=self.y_epoch)
         self.epoch += 1
+        if self.gram is not None:
+            self._refresh_gram()

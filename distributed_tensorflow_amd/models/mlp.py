@@ -85,6 +85,9 @@ class MLPEngine:
         self._graphs = {}
         self._eval_ws = None
         self._eval_acc = None
+        self._gram = None
+        self._pipe = None
+        self._pipe_bufs = None
 
     # -- data ---------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -106,6 +109,56 @@ class MLPEngine:
         if rebuilt:
             self._desc = None
             self._graphs.clear()
+
+    def bind_gram(self, gram: Optional[torch.Tensor]):
+        """Attach the Gram blocks of consecutive mini-batches of the bound (epoch-ordered) set:
+        ``gram[j, m, i] = 1 + x_{j+1}[m] . x_j[i]`` ([batches_per_epoch - 1, B, ld], zero for i >= B; see
+        :meth:`DeviceDataset.enable_pair_gram`).  With them, fused steps run with ONE launch per step
+        (``chunk_pipelined``).  The tensor is read in place: refresh its CONTENTS when the set is reshuffled."""
+        if gram is None:
+            self._gram = self._pipe = None
+            return
+        if not self.on_gpu:
+            raise ValueError("the pipelined chunk is a GPU path")
+        if gram.dtype != torch.float32 or not gram.is_contiguous() or gram.device != self.device:
+            raise ValueError("gram must be a contiguous float32 tensor on the engine's device")
+        nb, b, ld = gram.shape
+        if b != self.B or nb < self.batches_per_epoch - 1 or ld % 16 or not (self.B <= ld <= 128):
+            raise ValueError("gram shape does not match the bound set")
+        if not hb.mlp_chunk_pipelined_supported(self.B, self.K, self.H, self.C):
+            raise ValueError("shape not supported by the pipelined chunk")
+        self._gram = gram
+        self._pipe = None
+
+    @property
+    def pipelined(self) -> bool:
+        return self._gram is not None
+
+    def _pipe_descriptor(self) -> "hb.DtfPipeDesc":
+        if self._pipe is None:
+            if self._pipe_bufs is None:
+                dev = self.device
+                self._pipe_bufs = {
+                    "tW1": torch.empty_like(self.p["W1"]), "tb1": torch.empty_like(self.p["b1"]),
+                    "tW2": torch.empty_like(self.p["W2"]), "tb2": torch.empty_like(self.p["b2"]),
+                    "a2b": torch.zeros((self.B, self.H), dtype=torch.float32, device=dev),
+                    "zws3": torch.zeros((3 * 2048,), dtype=torch.float32, device=dev),
+                }
+            q = hb.DtfPipeDesc()
+            for k, t in self._pipe_bufs.items():
+                setattr(q, k, t.data_ptr())
+            q.gram = self._gram.data_ptr()
+            q.gram_ld = self._gram.shape[2]
+            self._pipe = q
+        return self._pipe
+
+    def chunk_pipelined(self, pos: int, n: int):
+        """Enqueue n fused steps on batches pos .. pos+n-1 of the epoch, one launch per step (no cursor change)."""
+        if self._gram is None:
+            raise RuntimeError("bind_gram() first")
+        if pos < 0 or pos + n > self.batches_per_epoch:
+            raise ValueError("a pipelined chunk must stay inside one epoch")
+        hb.mlp_chunk_pipelined(self._descriptor(), self._pipe_descriptor(), pos, n)
 
     def set_cursor(self, value: int):
         self._host_cursor = int(value)
@@ -202,6 +255,18 @@ class MLPEngine:
         if n <= 0:
             return
         pos = self._host_cursor % self.batches_per_epoch
+        if self.on_gpu and self._gram is not None and pos + n <= self.batches_per_epoch:
+            if not use_graph:
+                self.chunk_pipelined(pos, n)
+            else:
+                key = ("pipe", pos, n)
+                g = self._graphs.get(key)
+                if g is None:
+                    g = self._capture_pipe(pos, n)
+                    self._graphs[key] = g
+                g.replay()
+            self._host_cursor += n
+            return
         if not self.on_gpu or not use_graph:
             for i in range(n):
                 self.step_fused(pos + i)
@@ -242,6 +307,30 @@ class MLPEngine:
         with torch.cuda.graph(graph):
             for i in range(n):
                 hb.mlp_step_fused(self._desc, (pos + i) % self.batches_per_epoch, parity0 ^ (i & 1))
+        return graph
+
+    def _capture_pipe(self, pos: int, n: int) -> "torch.cuda.CUDAGraph":
+        self._descriptor()
+        # Warm up (module load) on a side stream with the training state rolled back afterwards.
+        saved = {k: v.clone() for k, v in self.p.items()}
+        saved_gs = self.global_step.clone() if self.global_step is not None else None
+        saved_hist = (self.loss_hist.clone(), self.acc_hist.clone())
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.chunk_pipelined(pos, min(n, 2))
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        for k, v in saved.items():
+            self.p[k].copy_(v)
+        if saved_gs is not None:
+            self.global_step.copy_(saved_gs)
+        self.loss_hist.copy_(saved_hist[0])
+        self.acc_hist.copy_(saved_hist[1])
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.chunk_pipelined(pos, n)
         return graph
 
     def reset_step_workspace(self, parity: int = 0):

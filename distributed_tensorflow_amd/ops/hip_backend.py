@@ -58,8 +58,26 @@ class DtfMlpDesc(C.Structure):
     ]
 
 
+class DtfPipeDesc(C.Structure):
+    """Mirror of ``struct DtfPipeDesc`` (state of the one-launch-per-step chunk)."""
+
+    _fields_ = [
+        ("tW1", C.c_void_p),
+        ("tb1", C.c_void_p),
+        ("tW2", C.c_void_p),
+        ("tb2", C.c_void_p),
+        ("a2b", C.c_void_p),
+        ("zws3", C.c_void_p),
+        ("gram", C.c_void_p),
+        ("gram_ld", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 def _declare(lib: C.CDLL) -> None:
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    lib.dtf_mlp_chunk_pipelined.argtypes = [C.POINTER(DtfMlpDesc), C.POINTER(DtfPipeDesc), i32, i32, vp]
+    lib.dtf_mlp_chunk_pipelined_supported.argtypes = [i32, i32, i32, i32]
     lib.dtf_mlp_step_fused.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, vp]
     lib.dtf_mlp_step_grad.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, vp]
     lib.dtf_advance_cursor.argtypes = [vp, i32, vp]
@@ -247,6 +265,16 @@ def mlp_eval(x, y, W1, b1, W2, b2, act: int, a2_ws, loss_sum, correct):
 def mlp_step_fused(desc: DtfMlpDesc, batch_index: int, parity: int):
     _check(require().dtf_mlp_step_fused(C.byref(desc), int(batch_index), int(parity), _stream()),
            "dtf_mlp_step_fused")
+
+
+def mlp_chunk_pipelined(desc: DtfMlpDesc, pipe: DtfPipeDesc, first_batch: int, n: int):
+    """n fused steps with one launch per step (csrc/mlp_step2.hip: step_pipe_kernel)."""
+    _check(require().dtf_mlp_chunk_pipelined(C.byref(desc), C.byref(pipe), int(first_batch), int(n), _stream()),
+           "dtf_mlp_chunk_pipelined")
+
+
+def mlp_chunk_pipelined_supported(B: int, K: int, H: int, Cn: int) -> bool:
+    return bool(require().dtf_mlp_chunk_pipelined_supported(int(B), int(K), int(H), int(Cn)))
 
 
 def mlp_step_grad(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float = 1.0):

@@ -175,19 +175,43 @@ class _BaseTrainer:
 class SingleTrainer(_BaseTrainer):
     name = "single"
 
-    def __init__(self, *a, **kw):
+    def __init__(self, *a, pipelined: bool = True, **kw):
         kw["need_grads"] = False
         super().__init__(*a, **kw)
         # fused path bumps global_step inside the head kernel
         self.engine.global_step = self.global_step
         self.engine._desc = None
+        # One launch per step: step t's backward and step t+1's forward share a kernel; needs the Gram
+        # blocks of consecutive mini-batches, which the resident dataset refreshes at every reshuffle.
+        self.pipelined = False
+        if (pipelined and self.device.type == "cuda" and hasattr(self.ds, "enable_pair_gram")
+                and hb.mlp_chunk_pipelined_supported(self.engine.B, self.engine.K, self.engine.H, self.engine.C)
+                and self.engine.batches_per_epoch >= 2):
+            self.engine.bind_gram(self.ds.enable_pair_gram())
+            self.pipelined = True
 
     def _one_step(self, batch_index: int):
         self.engine.step_fused(batch_index)
 
+    def _run_eager(self, pos: int, n: int):
+        if self.pipelined:
+            self.engine.chunk_pipelined(pos, n)
+            self.engine.advance(n)
+        else:
+            super()._run_eager(pos, n)
+
+    def _get_graph(self, pos: int, n: int, parity: int):
+        return super()._get_graph(pos, n, 0 if self.pipelined else parity)
+
+    def _capture(self, pos: int, n: int, parity: int):
+        if not self.pipelined:
+            return super()._capture(pos, n, parity)
+        return self.engine._capture_pipe(pos, n)     # chunk-local state only: the parity plays no role
+
     def describe(self):
-        return "single (no PS): 2 fused launches/step, hipGraph chunks of %d" % self.chunk if self.use_graph \
-            else "single (no PS): 2 fused launches/step, eager"
+        how = "1 launch/step (backward of step t + forward of step t+1 in one kernel)" if self.pipelined \
+            else "2 fused launches/step"
+        return f"single (no PS): {how}, " + ("hipGraph chunks of %d" % self.chunk if self.use_graph else "eager")
 
 
 class _CollectiveTrainer(_BaseTrainer):

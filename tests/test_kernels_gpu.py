@@ -189,3 +189,48 @@ def test_log_zero_edge_case_is_finite(step_path):
     eng.step_grad()
     torch.cuda.synchronize()
     assert torch.isfinite(eng.loss_hist[0]) and all(torch.isfinite(v).all() for v in eng.g.values())
+
+
+def _pair_gram(eng):
+    nb, B = eng.batches_per_epoch, eng.B
+    xb = eng.x[:nb * B].view(nb, B, -1)
+    ld = (B + 15) // 16 * 16
+    gram = torch.zeros(nb - 1, B, ld, device=eng.device)
+    gram[:, :, :B] = 1.0 + torch.bmm(xb[1:], xb[:-1].transpose(1, 2))
+    return gram
+
+
+@pytest.mark.parametrize("B,K,H,C,act", [(100, 784, 100, 10, "sigmoid"), (100, 784, 100, 10, "relu"),
+                                         (64, 256, 48, 10, "sigmoid"), (37, 100, 20, 7, "sigmoid"),
+                                         (128, 1024, 128, 16, "sigmoid")])
+@pytest.mark.parametrize("n", [1, 2, 5, 6])
+def test_pipelined_chunk_tracks_cpu_reference(B, K, H, C, act, n):
+    """One launch per step (the forward of step t+1 from the pre-update parameters plus the Gram correction)
+    gives the parameters, losses and step count of n ordinary fused steps."""
+    gpu = _engine(DEV, B, K, H, C, act, with_grads=False, nb=7)
+    cpu = _engine("cpu", B, K, H, C, act, with_grads=False, nb=7)
+    gpu.bind_gram(_pair_gram(gpu))
+    gpu.set_cursor(1)
+    cpu.set_cursor(1)
+    gpu.run_chunk(n, use_graph=False)
+    cpu.run_chunk(n, use_graph=False)
+    torch.cuda.synchronize()
+    for k in MLPEngine.PARAM_NAMES:
+        torch.testing.assert_close(gpu.p[k].cpu(), cpu.p[k], rtol=2e-4, atol=2e-5)
+    assert float(gpu.global_step) == float(n) and gpu._host_cursor == 1 + n
+    torch.testing.assert_close(gpu.loss_hist[1:1 + n].cpu(), cpu.loss_hist[1:1 + n], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(gpu.acc_hist[1:1 + n].cpu(), cpu.acc_hist[1:1 + n], rtol=0, atol=1e-6)
+
+
+def test_pipelined_chunk_graph_replay_and_two_launch_agree():
+    a = _engine(DEV, with_grads=False, nb=8)
+    b = _engine(DEV, with_grads=False, nb=8)
+    a.bind_gram(_pair_gram(a))
+    a.run_chunk(4, use_graph=True)
+    a.run_chunk(3, use_graph=True)       # odd chunk: starts from the twin parameter set
+    a.run_chunk(4, use_graph=True)       # crosses the epoch end: falls back to the two-launch step
+    b.run_chunk(11, use_graph=False)
+    torch.cuda.synchronize()
+    for k in MLPEngine.PARAM_NAMES:
+        torch.testing.assert_close(a.p[k], b.p[k], rtol=2e-4, atol=2e-5)
+    assert a._host_cursor == 11 and float(a.global_step) == 11.0
