@@ -161,7 +161,44 @@ def block_stamps():
     print("  bwd  per block (id: start/end): " + " ".join("%d:%d/%d" % (i, rel(b[i, 0]), rel(b[i, 1])) for i in range(nb)))
 
 
+def pipe_block_stamps():
+    """Per-block timeline of one launch of the one-launch-per-step kernel (forward tiles of step t+1 +
+    backward tiles of step t)."""
+    eng = make_engine()
+    lib = hb.require()
+    nb, B = eng.batches_per_epoch, eng.B
+    xb = eng.x[:nb * B].view(nb, B, -1)
+    gram = torch.zeros(nb - 1, B, (B + 15) // 16 * 16, device="cuda")
+    gram[:, :, :B] = 1.0 + torch.bmm(xb[1:], xb[:-1].transpose(1, 2))
+    eng.bind_gram(gram)
+    stamps = torch.zeros(2 * 1024, dtype=torch.int64, device="cuda")
+    lib.dtf_debug_set_block_stamps.argtypes = [C.c_void_p]
+    lib.dtf_debug_set_block_stamps.restype = None
+    eng.chunk_pipelined(0, 2)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    lib.dtf_debug_set_block_stamps(stamps.data_ptr())
+    with torch.cuda.graph(g):
+        eng.chunk_pipelined(0, 6)
+    lib.dtf_debug_set_block_stamps(None)
+    g.replay()
+    torch.cuda.synchronize()
+    s = stamps.cpu().view(-1, 2)
+    b, f = s[256:256 + 78], s[768:768 + 169]
+    t0 = int(min(f[:, 0].min(), b[:, 0].min()))
+    rel = lambda x: (int(x) - t0) * 10   # noqa: E731
+    print("one-launch step, second-to-last launch of a 6-step chunk (ns from the first block start):")
+    print("  fwd tiles  start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
+    print("  dW1 tiles  start %5d..%5d   end %5d..%5d" % (rel(b[:70, 0].min()), rel(b[:70, 0].max()), rel(b[:70, 1].min()), rel(b[:70, 1].max())))
+    print("  dW2 tiles + statistics (start/end): " + " ".join("%d/%d" % (rel(b[i, 0]), rel(b[i, 1])) for i in range(70, 78)))
+    durf = (f[:, 1] - f[:, 0]) * 10
+    durb = (b[:70, 1] - b[:70, 0]) * 10
+    print("  durations: fwd tiles min %d median %d max %d; dW1 tiles min %d median %d max %d" % (
+        int(durf.min()), int(durf.median()), int(durf.max()), int(durb.min()), int(durb.median()), int(durb.max())))
+
+
 if __name__ == "__main__":
+    pipe_block_stamps()
     block_stamps()
     bwd_stamps(1, "main block 1")
     bwd_stamps(-1, "stats block: 3=softmax done,4=db2,5=hist stores,6=global_step rmw")
