@@ -197,7 +197,40 @@ def pipe_block_stamps():
         int(durf.min()), int(durf.median()), int(durf.max()), int(durb.min()), int(durb.median()), int(durb.max())))
 
 
+def pipe_fwd_stamps(block=512 + 30):
+    """Phase stamps of one forward tile of the one-launch step."""
+    eng = make_engine()
+    lib = hb.require()
+    nb, B = eng.batches_per_epoch, eng.B
+    xb = eng.x[:nb * B].view(nb, B, -1)
+    gram = torch.zeros(nb - 1, B, (B + 15) // 16 * 16, device="cuda")
+    gram[:, :, :B] = 1.0 + torch.bmm(xb[1:], xb[:-1].transpose(1, 2))
+    eng.bind_gram(gram)
+    stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+    lib.dtf_debug_set_bwd_stamps.argtypes = [C.c_void_p]
+    lib.dtf_debug_set_bwd_stamp_block.argtypes = [C.c_int]
+    eng.chunk_pipelined(0, 2)
+    torch.cuda.synchronize()
+    lib.dtf_debug_set_bwd_stamps(stamps.data_ptr())
+    lib.dtf_debug_set_bwd_stamp_block(block)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.chunk_pipelined(0, 6)
+    lib.dtf_debug_set_bwd_stamps(None)
+    lib.dtf_debug_set_bwd_stamp_block(1)
+    g.replay()
+    torch.cuda.synchronize()
+    s = stamps.cpu().view(16, 2)
+    names = ["start", "offsets + loads issued", "stage + softmax (2 syncs)", "contraction + dz2 + a2^T dz3 (+sync)",
+             "correction + partials to LDS (+sync)", "reduce + activation + store (+sync)", "logit partials + atomics", "end"]
+    print("one-launch step, forward tile %d (thread 0): wall ns / shader cycles" % (block - 512))
+    for i in range(1, 8):
+        print("  %-40s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
+    print("  %-40s %7d ns" % ("total", (s[7, 0] - s[0, 0]) * 10))
+
+
 if __name__ == "__main__":
+    pipe_fwd_stamps()
     pipe_block_stamps()
     block_stamps()
     bwd_stamps(1, "main block 1")

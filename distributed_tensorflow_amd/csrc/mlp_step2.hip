@@ -1212,9 +1212,12 @@ struct PipeParams {
 // exceed the CUs of the chip, or some CUs run two workgroups and finish last (169 + 78 <= 256).
 constexpr int kPipeNA = 2;
 constexpr int kPipeFwdSlots = 4;      // 8 waves x 4 slots x 2 ranges = 64 macro-steps: K <= 1024
-constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 9 + 4 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
+constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 9 + 8 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
 
-template <int CQ>
+// NSM = full contraction slots per wave (8 waves x 2 ranges x NSM macro-steps of 16 k); TAIL: the
+// K - 256 NSM <= 64 remaining k are contracted by ONE 4-wide step per (wave, range) pair instead of a
+// mostly empty fourth slot (784 = 3 x 256 + 16: three slots and a tail on waves 0-1).
+template <int CQ, int NSM, bool TAIL>
 __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem, int tn, int tm, int lin) {
   const BwdParams& p = pp.b;
   float* red = smem;                         // [8 waves][4][64] (after the contraction)
@@ -1224,8 +1227,8 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   float* w2t = dz3s + 128 * kLdz;            // [32][17]: rows 0-7 = old W2 rows of the tile's columns
   float* dz2s = w2t + 32 * kLdw;             // [128][9] dz2 of step t, tile columns
   float* a2s = dz2s + 128 * 9;               // [128][9] a2 of step t, tile columns
-  float* w2n = a2s + 128 * 9;                // [4][8][16] partial sums of a2^T dz3
-  float* w2new = w2n + 4 * 8 * 16;           // [8][17] new W2 rows of the tile's columns
+  float* w2n = a2s + 128 * 9;                // [8 waves][8][16] partial sums of a2^T dz3
+  float* w2new = w2n + 8 * 8 * 16;           // [8][17] new W2 rows of the tile's columns
   float* psum = w2new + 8 * kLdw;            // [2][64]
   float* a2t = psum + 128;                   // [8][9] new activations
   float* b2s = a2t + 80;                     // [16]
@@ -1236,6 +1239,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   const int r8 = i16 & 7, g = i16 >> 3;
   const int m0 = tm * 8, n0 = tn * 8;
   DTF_BLOCK_STAMP_AT(p.bs, lin, 0);
+  DTF_STAMP2_AT(lin, 0);
   const float* __restrict__ Xn = p.xbase + pp.next_index * (long)M * (long)K;     // batch t+1
   const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;      // labels of batch t
   const float lr = *p.lr;
@@ -1283,10 +1287,10 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- group 3: the main operands (x' rows, old W1 columns): needed last, issued last ---------------------
-  unsigned xo[kPipeFwdSlots], wo[kPipeFwdSlots][4];
-  bool kok[kPipeFwdSlots];
+  unsigned xo[NSM], wo[NSM][4];
+  bool kok[NSM];
 #pragma unroll
-  for (int j = 0; j < kPipeFwdSlots; ++j) {
+  for (int j = 0; j < NSM; ++j) {
     const unsigned kb = (2u * (wave + j * kBwdWaves) + g) * 16u + q * 4u;
     kok[j] = kb < (unsigned)K;
     const unsigned kbc = kok[j] ? kb : K - 4;
@@ -1294,17 +1298,27 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
 #pragma unroll
     for (int s = 0; s < 4; ++s) wo[j][s] = (__umul24(kbc + s, H) + col_c) * 4u;
   }
+  const unsigned kt = 256u * NSM + 4u * (2u * wave + g) + q;        // tail: one k per lane
+  const bool kt_ok = TAIL && kt < (unsigned)K;
+  const unsigned ktc = kt_ok ? kt : K - 1;
+  const unsigned xto = (__umul24(row_c, K) + ktc) * 4u, wto = (__umul24(ktc, H) + col_c) * 4u;
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 a[kPipeFwdSlots];
-  float bv[kPipeFwdSlots][4];
+  f32x4 a[NSM];
+  float bv[NSM][4];
 #pragma unroll
-  for (int j = 0; j < kPipeFwdSlots; ++j) {
+  for (int j = 0; j < NSM; ++j) {
     a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Xn) + xo[j]);
 #pragma unroll
     for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(pp.W1r, wo[j][s]);
   }
+  float at = 0.f, bt = 0.f;
+  if (TAIL) {
+    at = ld_ub(Xn, xto);
+    bt = ld_ub(pp.W1r, wto);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
+  DTF_STAMP2_AT(lin, 1);
   // ---- phase 1: stage, softmax of step t -> dz3s -----------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -1356,37 +1370,66 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   }
   __syncthreads();
 
-  // ---- phase 2: dz2 of step t for the tile's columns; partial sums of a2^T dz3 (-> new W2 rows) ---------------
+  DTF_STAMP2_AT(lin, 2);
+  // ---- phase 2 (one basic block, so that the matrix pipe and the vector/LDS work overlap):
+  //   main contraction (operands in registers since phase 0),
+  //   dz2 of step t for the tile's columns,
+  //   a2^T dz3 for the tile's columns (-> new W2 rows) with LDS-fed MFMAs, eight waves splitting the batch.
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int e = tid + u * kBwdThreads;
-    const int j = e >> 3, c = e & 7;
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + j * kLdz);
-    float da = 0.f;
+  for (int j = 0; j < NSM; ++j) {
+    const bool ok = col_ok && kok[j];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
+  }
+  if (TAIL) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, (col_ok && kt_ok) ? bt : 0.f, acc0, 0, 0, 0);
+  {
+    const int c = tid & 7;                           // the same column for both elements of this thread
+    float w2row[4 * CQ];
 #pragma unroll
-    for (int qd = 0; qd < CQ; ++qd) {
-      const f32x4 d = d4[qd];
-      da += d[0] * w2t[c * kLdw + 4 * qd] + d[1] * w2t[c * kLdw + 4 * qd + 1] + d[2] * w2t[c * kLdw + 4 * qd + 2] +
-            d[3] * w2t[c * kLdw + 4 * qd + 3];
+    for (int k = 0; k < 4 * CQ; ++k) w2row[k] = w2t[c * kLdw + k];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = (tid + u * kBwdThreads) >> 3;
+      const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + j * kLdz);
+      float part[CQ];
+#pragma unroll
+      for (int qd = 0; qd < CQ; ++qd) {
+        const f32x4 d = d4[qd];
+        part[qd] = d[0] * w2row[4 * qd] + d[1] * w2row[4 * qd + 1] + d[2] * w2row[4 * qd + 2] + d[3] * w2row[4 * qd + 3];
+      }
+      float da = part[0];
+#pragma unroll
+      for (int qd = 1; qd < CQ; ++qd) da += part[qd];
+      dz2s[j * 9 + c] = da * dtf_act_bwd(a2s[j * 9 + c], p.act);      // rows >= M: dz3 == 0
     }
-    dz2s[j * 9 + c] = da * dtf_act_bwd(a2s[j * 9 + c], p.act);      // rows >= M: dz3 == 0
   }
   {
-    const int c = tid & 7, cls = (tid >> 3) & 15, part = tid >> 7;
-    float s = 0.f;
-#pragma unroll 8
-    for (int j = part; j < 128; j += 4) s += a2s[j * 9 + c] * dz3s[j * kLdz + cls];
-    w2n[(part * 8 + c) * 16 + cls] = s;
+    // D[h][cls] += sum_j a2[j][n0+h] dz3[j][cls]: A[i][kk=q] = a2s[j = 4 step + q][i] (i < 8), B[kk=q][col] = dz3s[j][col]
+    f32x4 wacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = 4 * (wave + t * kBwdWaves) + q;              // <= 127; rows >= M are zero in both operands
+      const float av = i16 < 8 ? a2s[j * 9 + r8] : 0.f;
+      wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dz3s[j * kLdz + i16], wacc, 0, 0, 0);
+    }
+    if (q < 2) {                                                  // D rows 4q + reg < 8
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) w2n[(wave * 8 + 4 * q + rg) * 16 + i16] = wacc[rg];
+    }
   }
   __syncthreads();
   if (tid < 128) {
     const int c = tid >> 4, cls = tid & 15;
-    const float s = w2n[c * 16 + cls] + w2n[(8 + c) * 16 + cls] + w2n[(16 + c) * 16 + cls] + w2n[(24 + c) * 16 + cls];
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBwdWaves; ++w) s += w2n[(w * 8 + c) * 16 + cls];
     w2new[c * kLdw + cls] = w2t[c * kLdw + cls] - lr * s;            // zero beyond H / C stays zero
   }
-
-  // ---- contraction: correction slot first (its operands are here), then the main slots -------------------------
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  DTF_STAMP2_AT(lin, 3);
+  // ---- correction slot: A = -lr * G1 rows, B = dz2 (LDS) ---------------------------------------------------------
   {
     const bool ok = col_ok && jok;
     const unsigned jc = jok ? jb : 0u;
@@ -1395,41 +1438,30 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[2], ok ? dz2s[(jc + 2) * 9 + r8] : 0.f, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[3], ok ? dz2s[(jc + 3) * 9 + r8] : 0.f, acc1, 0, 0, 0);
   }
-#pragma unroll
-  for (int j = 0; j < kPipeFwdSlots; ++j) {
-    const bool ok = col_ok && kok[j];
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
-  }
   const f32x4 acc = acc0 + acc1;
   const float badd = (wave == 0 && g == 0) ? bias : 0.f;
   // (zs / ys, which red aliases, were last read before the two barriers above)
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) red[(wave * 4 + rg) * 64 + lane] = acc[rg] + badd;
   __syncthreads();
-  if (tid < 128) {
-    const int blk = tid >> 6, r = (tid >> 3) & 7, c = tid & 7;
-    const int drow = 8 * blk + r, dcol = 8 * blk + c;
-    const int rg = drow & 3, ln = ((drow >> 2) << 4) | dcol;
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + rg) * 64 + ln];
-    psum[blk * 64 + (tid & 63)] = s;
-  }
-  __syncthreads();
+  DTF_STAMP2_AT(lin, 4);
   if (tid < 64) {
     const int r = tid >> 3, c = tid & 7;
     const int orow = m0 + r, ocol = n0 + c;
+    // both diagonal blocks of the eight waves' partial tiles: D[r][c] and D[8 + r][8 + c]
+    const int rg = r & 3, ln0 = ((r >> 2) << 4) | c, ln1 = (((8 + r) >> 2) << 4) | (8 + c);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + rg) * 64 + ln0] + red[(w * 4 + rg) * 64 + ln1];
     float av = 0.f;
     if (orow < M && ocol < H) {
-      av = fast_act(psum[tid] + psum[64 + tid], p.act);
+      av = fast_act(s, p.act);
       pp.a2_next[(long)orow * H + ocol] = av;
     }
     a2t[r * 9 + c] = av;
   }
   __syncthreads();
+  DTF_STAMP2_AT(lin, 5);
   if (tid < 128) {
     const int r = tid >> 4, cls = tid & 15;
     if (m0 + r < M && cls < C) {
@@ -1439,17 +1471,19 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
       atomicAdd(&pp.zacc_next[(m0 + r) * 16 + cls], z);
     }
   }
+  DTF_STAMP2_AT(lin, 6);
+  DTF_STAMP2_AT(lin, 7);
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
-template <int CQ>
+template <int CQ, int NSM, bool TAIL>
 __global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp, int parts) {
   constexpr int kSmem = kPipeFwdSmem > bwd16_smem_floats(kPipeNA) ? kPipeFwdSmem : bwd16_smem_floats(kPipeNA);
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
   const int by = blockIdx.y, bx = blockIdx.x;
   if (by < pp.fwd_rows) {                       // forward tile of step t+1
     if (bx >= pp.tiles_n8 || !(parts & 1)) return;
-    pipe_fwd_body<CQ>(pp, smem, bx, by, 512 + by * pp.tiles_n8 + bx);
+    pipe_fwd_body<CQ, NSM, TAIL>(pp, smem, bx, by, 512 + by * pp.tiles_n8 + bx);
     return;
   }
   if (bx >= pp.tiles_h16 || !(parts & 2)) return;               // backward part of step t
@@ -1670,10 +1704,16 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     pp.tiles_n8 = tiles_n8;
     pp.tiles_h16 = tiles_h16;
     const dim3 grid(tiles_n8 > tiles_h16 ? tiles_n8 : tiles_h16, pp.fwd_rows + tiles_k + 2), block(kBwdThreads);
-    if (cq <= 3) {
-      hipLaunchKernelGGL((step_pipe_kernel<3>), grid, block, 0, stream, pp, g_pipe_parts);
+    // three full slots + a tail step when K = 768 + (<= 64); the generic form has four slots (K <= 1024)
+    const bool tail3 = K >= 768 && K - 768 <= 64;
+    if (cq <= 3 && tail3) {
+      hipLaunchKernelGGL((step_pipe_kernel<3, 3, true>), grid, block, 0, stream, pp, g_pipe_parts);
+    } else if (cq <= 3) {
+      hipLaunchKernelGGL((step_pipe_kernel<3, 4, false>), grid, block, 0, stream, pp, g_pipe_parts);
+    } else if (tail3) {
+      hipLaunchKernelGGL((step_pipe_kernel<4, 3, true>), grid, block, 0, stream, pp, g_pipe_parts);
     } else {
-      hipLaunchKernelGGL((step_pipe_kernel<4>), grid, block, 0, stream, pp, g_pipe_parts);
+      hipLaunchKernelGGL((step_pipe_kernel<4, 4, false>), grid, block, 0, stream, pp, g_pipe_parts);
     }
     cur = nxt;
   }

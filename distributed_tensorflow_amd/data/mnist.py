@@ -186,72 +186,175 @@ def read_data_sets(train_dir: str = "MNIST_data", one_hot: bool = True, seed: in
                     DataSet(te_i, conv(te_l), shuffle_seed), source)
 
 
+def _background_stream(device: torch.device):
+    """A HIP stream confined to 16 of the 256 CUs (hipExtStreamCreateWithCUMask), for work that should trickle
+    along beside latency-critical kernels: the next epoch's gather and Gram GEMM take a good part of an epoch
+    on 16 CUs and leave the other 240 to the training step, instead of sweeping over the whole chip for
+    0.5 ms (which slows every training kernel that runs meanwhile).  The mask enables whole groups of 8
+    consecutive CU bits — one CU on each XCD; sparser masks are refused by the runtime."""
+    try:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        mask = (ctypes.c_uint32 * 1)(0xFFFF)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(1), mask)
+            hip.hipGetLastError()                          # a refusal must not linger as the "last error"
+        if rc == 0 and handle.value:
+            return torch.cuda.ExternalStream(handle.value, device=device)
+    except Exception:  # noqa: BLE001 — fall through to an ordinary stream
+        pass
+    return torch.cuda.Stream(device=device)
+
+
 class DeviceDataset:
     """A split held on the training device, reshuffled per epoch without touching the host.
 
-    ``x_epoch`` / ``y_epoch`` are the tensors an :class:`MLPEngine` binds to; the
-    storage never moves, so hipGraphs captured against it stay valid across
-    epochs.  Every worker shuffles independently (no sharding between workers —
-    reference tfdist_between.py:92 draws from a private copy of the set).
+    ``x_epoch`` / ``y_epoch`` are the tensors an :class:`MLPEngine` binds to.  Every worker shuffles
+    independently (no sharding between workers — reference tfdist_between.py:92 draws from a private
+    copy of the set).
+
+    Single-buffered (default): the epoch order is rewritten in place by a gather kernel at every
+    ``shuffle_epoch()``; the storage never moves, so hipGraphs captured against it stay valid.
+
+    ``double_buffer=True``: two epoch-ordered copies.  While the trainer works through one, the NEXT
+    epoch's order (gather of 172 MB, and the Gram blocks if enabled) is produced into the other on a
+    side stream; ``shuffle_epoch()`` then only waits for that stream and flips ``active``.  Users capture
+    one set of graphs per buffer (``set_tensors(i)``, ``active``).  Measured on MI355X with the 8.7 us
+    training step this is SLOWER than refreshing in place (0.28 ms of GPU work per epoch): every step
+    needs all of its workgroups to finish, so anything that shares CUs with it for a while — on the whole
+    chip, or on a 16-CU masked stream — lengthens every step it overlaps.  It pays for slower steps
+    (PS transports), which is why it stays an option and is off by default.
     """
 
-    def __init__(self, images, labels, device, batch_size: int, seed: int = 0):
+    def __init__(self, images, labels, device, batch_size: int, seed: int = 0, double_buffer: bool = False):
         self.device = torch.device(device)
         self.x = torch.as_tensor(images, dtype=torch.float32).contiguous().to(self.device)
         self.y = torch.as_tensor(labels, dtype=torch.float32).contiguous().to(self.device)
         self.num_examples = self.x.shape[0]
         self.batch_size = int(batch_size)
         self.batches_per_epoch = self.num_examples // self.batch_size
-        self.x_epoch = torch.empty_like(self.x)
-        self.y_epoch = torch.empty_like(self.y)
+        self.double_buffer = bool(double_buffer) and self.device.type == "cuda"
+        self._sets = [self._new_set() for _ in range(2 if self.double_buffer else 1)]
+        self.active = 0
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed)
-        self.epoch = -1
-        self.gram = None
-        self.shuffle_epoch()
+        self._with_gram = False
+        self._staged_perm = None
+        self._side = _background_stream(self.device) if self.double_buffer else None
+        self._ready = None
+        self._fill(0)
+        self.epoch = 0
+        if self.double_buffer:
+            self._prefetch()
+
+    # -- buffers ------------------------------------------------------------------------------
+    def _new_set(self):
+        return {"x": torch.empty_like(self.x), "y": torch.empty_like(self.y), "gram": None, "tmp": None}
+
+    def set_tensors(self, index: int):
+        """(x_epoch, y_epoch, gram) of buffer ``index`` (0, or 0/1 when double-buffered)."""
+        s = self._sets[index]
+        return s["x"], s["y"], s["gram"]
+
+    @property
+    def x_epoch(self) -> torch.Tensor:
+        return self._sets[self.active]["x"]
+
+    @property
+    def y_epoch(self) -> torch.Tensor:
+        return self._sets[self.active]["y"]
+
+    @property
+    def gram(self) -> Optional[torch.Tensor]:
+        return self._sets[self.active]["gram"]
+
+    # -- producing one epoch order ------------------------------------------------------------------
+    def _fill(self, index: int):
+        """Next permutation of the generator -> buffer ``index`` (and its Gram blocks), on the current stream."""
+        s = self._sets[index]
+        perm = self._take_perm()
+        if self.device.type == "cuda":
+            from ..ops import hip_backend as hb
+            hb.gather_rows(self.x, perm, s["x"])
+            hb.gather_rows(self.y, perm, s["y"])
+        else:
+            torch.index_select(self.x, 0, perm, out=s["x"])
+            torch.index_select(self.y, 0, perm, out=s["y"])
+        if self._with_gram:
+            self._fill_gram(s)
+        self._stage_perm()          # next epoch's order: host work and copy happen behind the queued GPU work
+
+    def _take_perm(self) -> torch.Tensor:
+        """The permutation of this epoch, already on the device: it is drawn and copied (pinned, asynchronous)
+        right after the previous one was used, so a reshuffle neither waits for the host nor drains the
+        stream with a blocking copy."""
+        if self._staged_perm is None:
+            self._stage_perm()
+        perm = self._staged_perm
+        self._staged_perm = None
+        return perm
+
+    def _stage_perm(self):
+        if self.device.type != "cuda":
+            self._staged_perm = torch.randperm(self.num_examples, generator=self._gen)
+            return
+        if getattr(self, "_pinned", None) is None:      # two pinned staging buffers, used alternately
+            self._pinned = [torch.empty(self.num_examples, dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._pin_turn = 0
+        host = self._pinned[self._pin_turn]
+        self._pin_turn ^= 1
+        torch.randperm(self.num_examples, generator=self._gen, out=host)
+        self._staged_perm = host.to(self.device, non_blocking=True)
+
+    def _fill_gram(self, s):
+        nb, b = self.batches_per_epoch, self.batch_size
+        if nb < 2:
+            return
+        if s["gram"] is None:
+            ld = (b + 15) // 16 * 16
+            s["gram"] = torch.zeros((nb - 1, b, ld), dtype=torch.float32, device=self.device)
+            s["tmp"] = torch.empty((nb - 1, b, b), dtype=torch.float32, device=self.device)
+        xb = s["x"][:nb * b].view(nb, b, -1)
+        # fp32 matrix units (no reduced-precision shortcut): the block enters the forward pass exactly
+        ones = torch.ones((1, 1, 1), dtype=torch.float32, device=self.device)
+        torch.baddbmm(ones, xb[1:], xb[:-1].transpose(1, 2), out=s["tmp"])
+        s["gram"][:, :, :b].copy_(s["tmp"])
+
+    def _prefetch(self):
+        """Produce the next epoch's order into the inactive buffer on the side stream."""
+        main = torch.cuda.current_stream(self.device)
+        released = torch.cuda.Event()
+        released.record(main)                      # work already queued may still read the inactive buffer
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(released)
+            self._fill(self.active ^ 1)
+            self._ready = torch.cuda.Event()
+            self._ready.record(self._side)
 
     def enable_pair_gram(self) -> torch.Tensor:
         """Keep ``gram[j, m, i] = 1 + x_{j+1}[m] . x_j[i]`` for every pair of consecutive mini-batches of the
-        epoch order ([batches_per_epoch - 1, B, ld], ld = B rounded up to 16, zero for i >= B), refreshed in
-        place by every reshuffle with one batched GEMM.  It is what lets a fused training step run as ONE
-        kernel launch (``MLPEngine.bind_gram``): the forward of batch j+1 is computed from the parameters
-        before the update of batch j plus a correction through this block."""
-        if self.gram is None:
-            ld = (self.batch_size + 15) // 16 * 16
-            self.gram = torch.zeros((max(self.batches_per_epoch - 1, 1), self.batch_size, ld),
-                                    dtype=torch.float32, device=self.device)
-            self._refresh_gram()
+        epoch order ([batches_per_epoch - 1, B, ld], ld = B rounded up to 16, zero for i >= B), refreshed
+        with every new order by one batched GEMM.  It is what lets a fused training step run as ONE kernel
+        launch (``MLPEngine.bind_gram``): the forward of batch j+1 is computed from the parameters before
+        the update of batch j plus a correction through this block."""
+        if not self._with_gram:
+            self._with_gram = True
+            self._fill_gram(self._sets[self.active])
+            if self.double_buffer:
+                with torch.cuda.stream(self._side):        # after the prefetch already queued there
+                    self._fill_gram(self._sets[self.active ^ 1])
+                    self._ready = torch.cuda.Event()
+                    self._ready.record(self._side)
+                torch.cuda.current_stream(self.device).wait_event(self._ready)   # allocations are visible to both
         return self.gram
 
-    def _refresh_gram(self):
-        nb, b = self.batches_per_epoch, self.batch_size
-        if self.gram is None or nb < 2:
-            return
-        xb = self.x_epoch[:nb * b].view(nb, b, -1)
-        # fp32 matrix units (no reduced-precision shortcut): the block enters the forward pass exactly
-        torch.baddbmm(self._gram_ones(), xb[1:], xb[:-1].transpose(1, 2), out=self._gram_tmp())
-        self.gram[:, :, :b].copy_(self._gram_tmp_t)
-
-    def _gram_ones(self):
-        if getattr(self, "_gram_ones_t", None) is None:
-            self._gram_ones_t = torch.ones((1, 1, 1), dtype=torch.float32, device=self.device)
-        return self._gram_ones_t
-
-    def _gram_tmp(self):
-        if getattr(self, "_gram_tmp_t", None) is None:
-            nb, b = self.batches_per_epoch, self.batch_size
-            self._gram_tmp_t = torch.empty((nb - 1, b, b), dtype=torch.float32, device=self.device)
-        return self._gram_tmp_t
-
     def shuffle_epoch(self):
-        perm = torch.randperm(self.num_examples, generator=self._gen).to(self.device)
-        if self.device.type == "cuda":
-            from ..ops import hip_backend as hb
-            hb.gather_rows(self.x, perm, self.x_epoch)
-            hb.gather_rows(self.y, perm, self.y_epoch)
+        if self.double_buffer:
+            torch.cuda.current_stream(self.device).wait_event(self._ready)
+            self.active ^= 1
+            self._prefetch()
         else:
-            torch.index_select(self.x, 0, perm, out=self.x_epoch)
-            torch.index_select(self.y, 0, perm, out=self.y_epoch)
+            self._fill(0)
         self.epoch += 1
-        if self.gram is not None:
-            self._refresh_gram()

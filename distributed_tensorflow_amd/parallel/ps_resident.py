@@ -54,6 +54,7 @@ class PsResidentTrainer(_BaseTrainer):
                                 {r: self.layout.view(self.grads, n) for r, n in names.items()},
                                 batch=batch, lr=self.lr_value, act=m["act"])
         self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self._bound_set = getattr(dataset, "active", 0)
         self.lr = self.engine.lr
         self.steps_done = 0
         self._graphs = {}

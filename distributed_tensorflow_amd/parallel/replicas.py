@@ -61,6 +61,7 @@ class _BaseTrainer:
             batch=batch, lr=lr, act=act, global_step=None,
         )
         self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self._bound_set = getattr(dataset, "active", 0)
         self.lr = self.engine.lr
         self.steps_done = 0
         self._graphs = {}
@@ -84,6 +85,27 @@ class _BaseTrainer:
             n -= k
         return out
 
+    # -- dataset buffers (a double-buffered DeviceDataset alternates between two epoch-ordered copies) ----
+    def _bind_set(self, index: int):
+        if index == self._bound_set:
+            return
+        x, y, gram = self.ds.set_tensors(index)
+        self.engine.bind_data(x, y)
+        if getattr(self, "pipelined", False):
+            self.engine.bind_gram(gram)
+        self._bound_set = index
+
+    def _set_at(self, cursor: int) -> int:
+        """Dataset buffer that will be active when the step counter reads ``cursor``."""
+        active = getattr(self.ds, "active", 0)
+        if not getattr(self.ds, "double_buffer", False):
+            return active
+        bpe = self.engine.batches_per_epoch
+        now = self.engine._host_cursor
+        # the buffers flip at every epoch boundary crossed between now and then
+        flips = (cursor // bpe) - (now // bpe) + (1 if (now % bpe == 0 and now > 0 and cursor >= now) else 0)
+        return active ^ (flips & 1)
+
     def prepare(self, steps_hint=()):
         """Capture every chunk graph the hinted run_steps() calls will need, outside any timed region."""
         if not self.use_graph:
@@ -94,12 +116,13 @@ class _BaseTrainer:
         keys = set()
         for n in steps_hint:
             for k in self._schedule(cursor, n):
-                keys.add((cursor % bpe, k, parity))
+                keys.add((cursor % bpe, k, parity, self._set_at(cursor)))
                 cursor += k
                 parity ^= k & 1
-        live = self.engine.parity
-        for pos, k, par in sorted(keys):
-            self._get_graph(pos, k, par)
+        live, live_set = self.engine.parity, self._bound_set
+        for pos, k, par, st in sorted(keys):
+            self._get_graph(pos, k, par, st)
+        self._bind_set(live_set)
         self.engine.reset_step_workspace(live)
 
     def _run_eager(self, pos: int, n: int):
@@ -107,10 +130,12 @@ class _BaseTrainer:
             self._one_step(pos + i)
         self.engine.advance(n)
 
-    def _get_graph(self, pos: int, n: int, parity: int):
-        key = (pos, n, parity)
+    def _get_graph(self, pos: int, n: int, parity: int, dset: int = None):
+        dset = self._bound_set if dset is None else dset
+        key = (pos, n, parity, dset)
         g = self._graphs.get(key)
         if g is None:
+            self._bind_set(dset)
             g = self._capture(pos, n, parity)
             self._graphs[key] = g
         return g
@@ -154,6 +179,7 @@ class _BaseTrainer:
             cur = self.engine._host_cursor
             if cur % bpe == 0 and cur > 0:
                 self.ds.shuffle_epoch()
+            self._bind_set(getattr(self.ds, "active", 0))
             if self.use_graph:
                 self._get_graph(cur % bpe, k, self.engine.parity).replay()
                 self.engine.parity ^= k & 1
@@ -200,8 +226,8 @@ class SingleTrainer(_BaseTrainer):
         else:
             super()._run_eager(pos, n)
 
-    def _get_graph(self, pos: int, n: int, parity: int):
-        return super()._get_graph(pos, n, 0 if self.pipelined else parity)
+    def _get_graph(self, pos: int, n: int, parity: int, dset: int = None):
+        return super()._get_graph(pos, n, 0 if self.pipelined else parity, dset)
 
     def _capture(self, pos: int, n: int, parity: int):
         if not self.pipelined:
