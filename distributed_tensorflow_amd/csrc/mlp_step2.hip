@@ -860,12 +860,114 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
 // The a2 operand has the same lane mapping in both roles, so — as in bwd_all_kernel — every
 // block executes one straight-line sequence of loads.  dz2 is formed once per (row, column)
 // and feeds both MFMAs: half the dot products of the 32x32 tiling.
+// Softmax inputs straight into registers: thread (row = tid >> 2, part = tid & 3) owns classes
+// 4 part .. 4 part + 3 of batch row `row` — the logits as ONE 16-byte load (the accumulator is a
+// [128][16] image, always in bounds), labels and output bias clamped into their buffers and masked at
+// use.  No LDS staging and no barrier before the softmax.  YV2: labels as two 8-byte loads (C even and
+// an 8-byte aligned label matrix), else four 4-byte loads.
+struct SmaxIn {
+  f32x4 z;
+  float y[4];
+  float b[4];
+};
+
+template <bool YV2>
+__device__ __forceinline__ SmaxIn smax_load(const float* __restrict__ zacc, const float* __restrict__ Y,
+                                            const float* __restrict__ b2r, int tid, int M, int C) {
+  const unsigned row = tid >> 2, c0 = 4u * (tid & 3);
+  const unsigned yrow = __umul24(umin_(row, M - 1), C);
+  unsigned yo[4], bo[4];
+  if (YV2) {
+    yo[0] = (yrow + umin_(c0, C - 2)) * 4u;
+    yo[2] = (yrow + umin_(c0 + 2, C - 2)) * 4u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yo[i] = (yrow + umin_(c0 + i, C - 1)) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bo[i] = umin_(c0 + i, C - 1) * 4u;
+  SmaxIn in;
+  in.z = *reinterpret_cast<const f32x4*>(zacc + 4 * tid);
+  if (YV2) {
+    const float2 y01 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(Y) + yo[0]);
+    const float2 y23 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(Y) + yo[2]);
+    in.y[0] = y01.x; in.y[1] = y01.y; in.y[2] = y23.x; in.y[3] = y23.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in.y[i] = ld_ub(Y, yo[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) in.b[i] = ld_ub(b2r, bo[i]);
+  return in;
+}
+
+// dz3 of the thread's four classes (written to dz3s by the caller) and, on request, the row's loss and
+// correct-prediction flag (every lane of a quad ends with the row values).  With YV2 a clamped label
+// pair may sit one or two classes left of its nominal place: such pairs lie wholly beyond C and are masked.
+template <bool YV2>
+__device__ __forceinline__ f32x4 smax_dz3(const SmaxIn& in, int tid, int M, int C, float inv_batch, bool want_stats,
+                                          float& row_loss, float& row_correct) {
+  const int row = tid >> 2, part = tid & 3;
+  const bool row_ok = row < M;
+  float z[4], y[4], ex[4];
+  float mx = -INFINITY, ysum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool ok = 4 * part + i < C;
+    z[i] = in.z[i] + (ok ? in.b[i] : 0.f);
+    y[i] = (ok && row_ok) ? in.y[i] : 0.f;
+    mx = fmaxf(mx, ok ? z[i] : -INFINITY);
+    ysum += y[i];
+  }
+  mx = fmaxf(mx, dpp_f<kXor1>(mx));
+  mx = fmaxf(mx, dpp_f<kXor2>(mx));
+  ysum += dpp_f<kXor1>(ysum);
+  ysum += dpp_f<kXor2>(ysum);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
+    se += ex[i];
+  }
+  se += dpp_f<kXor1>(se);
+  se += dpp_f<kXor2>(se);
+  const float inv = fast_rcp(se) * ysum;
+  f32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
+  row_loss = 0.f;
+  row_correct = 0.f;
+  if (want_stats) {   // block-uniform
+    const float lse = mx + fast_log(se);
+    float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
+    int az = 0, ay = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * part + i;
+      if (c < C) {
+        rloss -= y[i] * (z[i] - lse);
+        if (z[i] > bz) { bz = z[i]; az = c; }     // strict > keeps the smallest index on ties
+        if (y[i] > by) { by = y[i]; ay = c; }
+      }
+    }
+    rloss += dpp_f<kXor1>(rloss);
+    rloss += dpp_f<kXor2>(rloss);
+    argmax_step<kXor1>(bz, az);
+    argmax_step<kXor2>(bz, az);
+    argmax_step<kXor1>(by, ay);
+    argmax_step<kXor2>(by, ay);
+    row_loss = row_ok ? rloss : 0.f;
+    row_correct = (row_ok && az == ay) ? 1.f : 0.f;
+  }
+  return out;
+}
+
 // NA = 16-row sub-tiles of dW1 per workgroup (tile = 16 NA rows x 16 columns).
 constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * 64 > 2 * 128 * kLdw ? 8 * NA * 4 * 64 : 2 * 128 * kLdw; }
 constexpr int bwd16_smem_floats(int NA) { return bwd16_red_floats(NA) + 128 * kLdz + 32 * kLdw + 256 + 64; }
 
 // (bx, by) = position in the backward part of the grid, `lin` = linear id for the profiling stamps.
-template <int NS, int CQ, int NA>
+template <int NS, int CQ, int NA, bool YV2>
 __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
   constexpr int kTileRows = 16 * NA;
@@ -897,22 +999,10 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   const float* __restrict__ X = p.xbase + p.batch_index * (long)M * (long)K;
   const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;
   const float lr = *p.lr;
-  const unsigned y_max = (unsigned)M * C - 1;
-  unsigned yo[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned e = tid + u * kBwdThreads;
-    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
-  }
   const unsigned b2o = umin_(tid, C - 1) * 4u;
   const unsigned w2o = umin_(__umul24(h0 + ((tid >> 4) & 15), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
   __builtin_amdgcn_sched_barrier(0);
-  float zreg[4], yreg[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
-    yreg[u] = ld_ub(Y, yo[u]);
-  }
+  const SmaxIn sin = smax_load<YV2>(p.zacc, Y, p.b2r, tid, M, C);
   const float b2raw = ld_ub(p.b2r, b2o);
   const float w2reg = ld_ub(p.W2r, w2o);
   __builtin_amdgcn_sched_barrier(0);
@@ -963,76 +1053,21 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   __builtin_amdgcn_sched_barrier(0);
 
   DTF_STAMP2_AT(lin, 1);
-  // ---- phase 1: stage logits/labels, then softmax-xent ----------------------------------------
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * kBwdThreads;       // all 128 rows are staged: rows >= M as zeros
-    const bool ok = (e >> 4) < M && (e & 15) < C;
-    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
-    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
-  }
+  // ---- phase 1: softmax-xent from registers; the W2 tile is staged for phase 2 ---------------------
   // every thread stages its W2 load (rows 16-31 repeat rows 0-15 and are not read)
   w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + ((tid >> 4) & 15) < H && (tid & 15) < C) ? w2reg : 0.f;
   if (tid < 16) {
     b2s[tid] = tid < C ? b2raw : 0.f;
     db2s[tid] = 0.f;
   }
-  __syncthreads();
   const float inv_batch = 1.0f / (float)M;
   {
-    const int row = tid >> 2, part = tid & 3;      // 128 rows: every row of dz3s is written
-    const bool row_ok = row < M;
-    float z[4], y[4], ex[4];
-    float mx = -INFINITY, ysum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = 4 * part + i;
-      z[i] = zs[row * kLdw + c] + b2s[c];
-      y[i] = ys[row * kLdw + c];
-      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
-      ysum += y[i];
-    }
-    mx = fmaxf(mx, dpp_f<kXor1>(mx));
-    mx = fmaxf(mx, dpp_f<kXor2>(mx));
-    ysum += dpp_f<kXor1>(ysum);
-    ysum += dpp_f<kXor2>(ysum);
-    float se = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
-      se += ex[i];
-    }
-    se += dpp_f<kXor1>(se);
-    se += dpp_f<kXor2>(se);
-    const float inv = fast_rcp(se) * ysum;
-    f32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
-    *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
-    if (stats_block) {   // block-uniform
-      const float lse = mx + fast_log(se);
-      float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
-      int az = 0, ay = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = 4 * part + i;
-        if (c < C) {
-          rloss -= y[i] * (z[i] - lse);
-          if (z[i] > bz) { bz = z[i]; az = c; }
-          if (y[i] > by) { by = y[i]; ay = c; }
-        }
-      }
-      rloss += dpp_f<kXor1>(rloss);
-      rloss += dpp_f<kXor2>(rloss);
-      argmax_step<kXor1>(bz, az);
-      argmax_step<kXor2>(bz, az);
-      argmax_step<kXor1>(by, ay);
-      argmax_step<kXor2>(by, ay);
-      if (part == 0) {
-        rowstat[row] = row_ok ? rloss : 0.f;
-        rowstat[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
-      }
+    float rl, rc;
+    const f32x4 out = smax_dz3<YV2>(sin, tid, M, C, inv_batch, stats_block, rl, rc);
+    *reinterpret_cast<f32x4*>(dz3s + (tid >> 2) * kLdz + 4 * (tid & 3)) = out;      // 128 rows: all of dz3s
+    if (stats_block && (tid & 3) == 0) {
+      rowstat[tid >> 2] = rl;
+      rowstat[128 + (tid >> 2)] = rc;
     }
   }
   __syncthreads();
@@ -1165,10 +1200,10 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
-template <int NS, int CQ>
+template <int NS, int CQ, bool YV2>
 __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
-  bwd_tile16_body<NS, CQ, 2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
+  bwd_tile16_body<NS, CQ, 2, YV2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1217,7 +1252,7 @@ constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 *
 // NSM = full contraction slots per wave (8 waves x 2 ranges x NSM macro-steps of 16 k); TAIL: the
 // K - 256 NSM <= 64 remaining k are contracted by ONE 4-wide step per (wave, range) pair instead of a
 // mostly empty fourth slot (784 = 3 x 256 + 16: three slots and a tail on waves 0-1).
-template <int CQ, int NSM, bool TAIL>
+template <int CQ, int NSM, bool TAIL, bool YV2>
 __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem, int tn, int tm, int lin) {
   const BwdParams& p = pp.b;
   float* red = smem;                         // [8 waves][4][64] (after the contraction)
@@ -1248,14 +1283,6 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   const unsigned row_c = row < M ? row : M - 1, col_c = col_ok ? col : H - 1;
 
   // ---- group 1: what the softmax and dz2 of step t need ------------------------------------------
-  const unsigned y_max = (unsigned)M * C - 1;
-  unsigned yo[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned e = tid + u * kBwdThreads;
-    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
-  }
-  const unsigned b2o = umin_(tid, C - 1) * 4u;
   const unsigned w2o = umin_(__umul24(umin_(n0 + ((tid >> 4) & 7), H - 1), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
   unsigned aco[2];
 #pragma unroll
@@ -1264,14 +1291,9 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
     aco[u] = (__umul24(umin_(e >> 3, M - 1), H) + umin_(n0 + (e & 7), H - 1)) * 4u;
   }
   __builtin_amdgcn_sched_barrier(0);
-  float zreg[4], yreg[4], a2c[2];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
-    yreg[u] = ld_ub(Y, yo[u]);
-  }
-  const float b2raw = ld_ub(p.b2r, b2o);
+  const SmaxIn sin = smax_load<YV2>(p.zacc, Y, p.b2r, tid, M, C);
   const float w2reg = ld_ub(p.W2r, w2o);
+  float a2c[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) a2c[u] = ld_ub(p.a2, aco[u]);
   __builtin_amdgcn_sched_barrier(0);
@@ -1319,54 +1341,17 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   __builtin_amdgcn_sched_barrier(0);
 
   DTF_STAMP2_AT(lin, 1);
-  // ---- phase 1: stage, softmax of step t -> dz3s -----------------------------------------------------------
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * kBwdThreads;
-    const bool ok = (e >> 4) < M && (e & 15) < C;
-    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
-    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
-  }
+  // ---- phase 1: softmax of step t from registers -> dz3s; stage the W2 rows and the a2 column tile ---------
   w2t[(tid >> 4) * kLdw + (tid & 15)] = (n0 + ((tid >> 4) & 7) < H && (tid & 15) < C) ? w2reg : 0.f;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = tid + u * kBwdThreads;
     a2s[(e >> 3) * 9 + (e & 7)] = ((e >> 3) < M && n0 + (e & 7) < H) ? a2c[u] : 0.f;
   }
-  if (tid < 16) b2s[tid] = tid < C ? b2raw : 0.f;
-  __syncthreads();
-  const float inv_batch = 1.0f / (float)M;
   {
-    const int srow = tid >> 2, part = tid & 3;
-    const bool row_ok = srow < M;
-    float z[4], y[4], ex[4];
-    float mx = -INFINITY, ysum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = 4 * part + i;
-      z[i] = zs[srow * kLdw + c] + b2s[c];
-      y[i] = ys[srow * kLdw + c];
-      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
-      ysum += y[i];
-    }
-    mx = fmaxf(mx, dpp_f<kXor1>(mx));
-    mx = fmaxf(mx, dpp_f<kXor2>(mx));
-    ysum += dpp_f<kXor1>(ysum);
-    ysum += dpp_f<kXor2>(ysum);
-    float se = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
-      se += ex[i];
-    }
-    se += dpp_f<kXor1>(se);
-    se += dpp_f<kXor2>(se);
-    const float inv = fast_rcp(se) * ysum;
-    f32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
-    *reinterpret_cast<f32x4*>(dz3s + srow * kLdz + 4 * part) = out;
+    float rl, rc;
+    const f32x4 out = smax_dz3<YV2>(sin, tid, M, C, 1.0f / (float)M, false, rl, rc);
+    *reinterpret_cast<f32x4*>(dz3s + (tid >> 2) * kLdz + 4 * (tid & 3)) = out;
   }
   __syncthreads();
 
@@ -1476,19 +1461,19 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
-template <int CQ, int NSM, bool TAIL>
+template <int CQ, int NSM, bool TAIL, bool YV2>
 __global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp, int parts) {
   constexpr int kSmem = kPipeFwdSmem > bwd16_smem_floats(kPipeNA) ? kPipeFwdSmem : bwd16_smem_floats(kPipeNA);
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
   const int by = blockIdx.y, bx = blockIdx.x;
   if (by < pp.fwd_rows) {                       // forward tile of step t+1
     if (bx >= pp.tiles_n8 || !(parts & 1)) return;
-    pipe_fwd_body<CQ, NSM, TAIL>(pp, smem, bx, by, 512 + by * pp.tiles_n8 + bx);
+    pipe_fwd_body<CQ, NSM, TAIL, YV2>(pp, smem, bx, by, 512 + by * pp.tiles_n8 + bx);
     return;
   }
   if (bx >= pp.tiles_h16 || !(parts & 2)) return;               // backward part of step t
   const int byb = by - pp.fwd_rows;
-  bwd_tile16_body<4, CQ, kPipeNA>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
+  bwd_tile16_body<4, CQ, kPipeNA, YV2>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
 }
 
 bool g_bwd_tile16 = true;
@@ -1586,10 +1571,12 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + tiles_h + 1 + g_stamp_block;
   const dim3 grid(tiles_h, tiles_k + 2), block(kBwdThreads);
   if (g_bwd_tile16) {
-    if (cq <= 3) {
-      hipLaunchKernelGGL((bwd_tile16_kernel<4, 3>), grid, block, 0, stream, p);
+    // labels as 8-byte loads when every row pair is 8-byte aligned
+    const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
+    if (cq <= 3 && yv2) {
+      hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
     } else {
-      hipLaunchKernelGGL((bwd_tile16_kernel<4, 4>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((bwd_tile16_kernel<4, 4, false>), grid, block, 0, stream, p);
     }
   } else {
     const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves;
@@ -1706,14 +1693,15 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     const dim3 grid(tiles_n8 > tiles_h16 ? tiles_n8 : tiles_h16, pp.fwd_rows + tiles_k + 2), block(kBwdThreads);
     // three full slots + a tail step when K = 768 + (<= 64); the generic form has four slots (K <= 1024)
     const bool tail3 = K >= 768 && K - 768 <= 64;
-    if (cq <= 3 && tail3) {
-      hipLaunchKernelGGL((step_pipe_kernel<3, 3, true>), grid, block, 0, stream, pp, g_pipe_parts);
-    } else if (cq <= 3) {
-      hipLaunchKernelGGL((step_pipe_kernel<3, 4, false>), grid, block, 0, stream, pp, g_pipe_parts);
+    const bool fast = cq <= 3 && (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
+    if (fast && tail3) {
+      hipLaunchKernelGGL((step_pipe_kernel<3, 3, true, true>), grid, block, 0, stream, pp, g_pipe_parts);
+    } else if (fast) {
+      hipLaunchKernelGGL((step_pipe_kernel<3, 4, false, true>), grid, block, 0, stream, pp, g_pipe_parts);
     } else if (tail3) {
-      hipLaunchKernelGGL((step_pipe_kernel<4, 3, true>), grid, block, 0, stream, pp, g_pipe_parts);
+      hipLaunchKernelGGL((step_pipe_kernel<4, 3, true, false>), grid, block, 0, stream, pp, g_pipe_parts);
     } else {
-      hipLaunchKernelGGL((step_pipe_kernel<4, 4, false>), grid, block, 0, stream, pp, g_pipe_parts);
+      hipLaunchKernelGGL((step_pipe_kernel<4, 4, false, false>), grid, block, 0, stream, pp, g_pipe_parts);
     }
     cur = nxt;
   }
