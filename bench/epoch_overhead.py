@@ -1,3 +1,5 @@
+"""Step time of the device-resident single-GPU trainer inside an epoch and across epoch boundaries (the reshuffle
+gather and the Gram-block GEMM run between epochs)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.data import DeviceDataset, read_data_sets

@@ -1,3 +1,5 @@
+"""Fixed cost of one hipGraph chunk of the one-launch-per-step path (memset + stand-alone forward + graph launch):
+replays chunks of 200 / 50 / 10 / 2 steps and derives the per-chunk constant; also cycles 11 distinct graphs."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
