@@ -128,3 +128,47 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
         costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
     assert max(finals) == 2 * 22 * n_w
     assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
+
+
+def _single_trainer(double_buffer, pipelined, n=2200, batch=100, chunk=5):
+    import numpy as np
+
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import SingleTrainer
+
+    rng = np.random.RandomState(3)
+    x = rng.rand(n, 784).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.randint(0, 10, n)]
+    dev = torch.device("cuda")
+    ds = DeviceDataset(x, y, dev, batch, seed=11, double_buffer=double_buffer)
+    return SingleTrainer(device=dev, dataset=ds, batch=batch, lr=0.05, seed=1, chunk=chunk, use_graph=True,
+                         pipelined=pipelined)
+
+
+def test_one_launch_steps_equal_two_launch_steps_across_epochs():
+    """22 batches per epoch, 60 steps: the pipelined trainer (Gram blocks refreshed at every reshuffle, odd and even
+    chunks, chunk ends at epoch ends) follows the two-launch trainer."""
+    a = _single_trainer(False, True)
+    b = _single_trainer(False, False)
+    assert a.pipelined and not b.pipelined and "1 launch/step" in a.describe()
+    for n in (7, 22, 31):
+        a.run_steps(n)
+        b.run_steps(n)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.params, b.params, rtol=5e-4, atol=5e-5)
+    assert a.global_step_value() == b.global_step_value() == 60
+    assert abs(a.last_loss() - b.last_loss()) < 1e-3 * max(1.0, abs(b.last_loss()))
+
+
+def test_double_buffered_dataset_gives_the_same_run():
+    """The side-stream prefetch of the next epoch's order (two buffers, per-buffer graphs) does not change the run."""
+    a = _single_trainer(True, True)
+    b = _single_trainer(False, True)
+    assert a.ds.double_buffer and not b.ds.double_buffer
+    a.prepare(steps_hint=(50, 16))
+    for n in (50, 16):
+        a.run_steps(n)
+        b.run_steps(n)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.params, b.params, rtol=1e-5, atol=1e-6)
+    assert a.ds.epoch == b.ds.epoch == 2 and a.ds.active == 0
