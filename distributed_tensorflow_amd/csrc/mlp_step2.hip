@@ -1245,7 +1245,10 @@ struct PipeParams {
 
 // Backward tiles of the one-launch step are 80 x 16 (NA = 5): forward tiles + backward tiles must not
 // exceed the CUs of the chip, or some CUs run two workgroups and finish last (169 + 78 <= 256).
-constexpr int kPipeNA = 2;
+#ifndef DTF_PIPE_NA
+#define DTF_PIPE_NA 2
+#endif
+constexpr int kPipeNA = DTF_PIPE_NA;
 constexpr int kPipeFwdSlots = 4;      // 8 waves x 4 slots x 2 ranges = 64 macro-steps: K <= 1024
 constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 9 + 8 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
 

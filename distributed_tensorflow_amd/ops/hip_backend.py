@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent.parent / "_lib" / "libdtf_hip.so"
+_LIB_PATH = Path(os.environ.get("DTF_HIP_LIB") or Path(__file__).resolve().parent.parent / "_lib" / "libdtf_hip.so")   # DTF_HIP_LIB: a variant build (tuning experiments)
 _lib: Optional[C.CDLL] = None
 _load_error: Optional[str] = None
 

@@ -1,0 +1,54 @@
+"""DeviceDataset on the CPU: epoch reshuffles, staged permutations, Gram blocks of consecutive mini-batches."""
+import numpy as np
+import torch
+
+from distributed_tensorflow_amd.data import DeviceDataset
+
+
+def _data(n=1000, k=32, c=10, seed=0):
+    rng = np.random.RandomState(seed)
+    return rng.rand(n, k).astype(np.float32), np.eye(c, dtype=np.float32)[rng.randint(0, c, n)]
+
+
+def test_every_epoch_is_a_permutation_of_the_split_and_rows_keep_their_labels():
+    x, y = _data()
+    ds = DeviceDataset(x, y, "cpu", 100, seed=5)
+    key = {tuple(np.round(r, 6)): tuple(l) for r, l in zip(x, y)}
+    seen = []
+    for _ in range(3):
+        xe, ye = ds.x_epoch.numpy(), ds.y_epoch.numpy()
+        assert sorted(map(tuple, np.round(xe, 6))) == sorted(key)           # same rows, other order
+        assert all(key[tuple(np.round(r, 6))] == tuple(l) for r, l in zip(xe, ye))
+        seen.append(xe.copy())
+        ds.shuffle_epoch()
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    assert ds.epoch == 3 and ds.batches_per_epoch == 10
+
+
+def test_same_seed_same_orders_and_workers_differ():
+    x, y = _data()
+    a, b, c = (DeviceDataset(x, y, "cpu", 100, seed=s) for s in (7, 7, 8))
+    for _ in range(2):
+        assert torch.equal(a.x_epoch, b.x_epoch) and not torch.equal(a.x_epoch, c.x_epoch)
+        for d in (a, b, c):
+            d.shuffle_epoch()
+
+
+def test_pair_gram_is_one_plus_the_dot_products_of_consecutive_batches_and_follows_reshuffles():
+    x, y = _data(n=530, k=48)          # 5 batches of 100 (30 rows never used), ld = 112
+    ds = DeviceDataset(x, y, "cpu", 100, seed=1)
+    g = ds.enable_pair_gram()
+    assert g.shape == (4, 100, 112)
+    for _ in range(2):
+        xb = ds.x_epoch[:500].view(5, 100, -1)
+        for j in range(4):
+            torch.testing.assert_close(ds.gram[j, :, :100], 1.0 + xb[j + 1] @ xb[j].t(), rtol=1e-5, atol=1e-5)
+        assert float(ds.gram[:, :, 100:].abs().max()) == 0.0
+        ds.shuffle_epoch()
+    assert ds.gram.data_ptr() == g.data_ptr()          # refreshed in place: captured graphs stay valid
+
+
+def test_double_buffer_is_ignored_on_the_cpu():
+    x, y = _data()
+    ds = DeviceDataset(x, y, "cpu", 100, seed=1, double_buffer=True)
+    assert not ds.double_buffer and ds.active == 0 and ds.set_tensors(0)[0] is ds.x_epoch
