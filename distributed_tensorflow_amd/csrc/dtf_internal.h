@@ -37,3 +37,6 @@ struct DtfMlpDesc;
 bool dtf_step2_supported(int B, int K, int H, int C);
 int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
                      hipStream_t stream);
+
+// p[0..n) = 0 with a kernel launch (captured faithfully by stream captures, unlike hipMemsetAsync here).
+int dtf_launch_zero(float* p, long n, hipStream_t stream);

@@ -61,9 +61,9 @@ int run_step(const DtfMlpDesc* d, int bias, int parity, int head_mode, float gra
     if (d->loss_hist)
       hipLaunchKernelGGL(zero_hist_slot_kernel, dim3(1), dim3(64), 0, stream, d->cursor, bias,
                          d->loss_hist, d->acc_hist, d->hist_cap);
-    if (hipMemsetAsync(d->gW2, 0, sizeof(float) * H * C, stream) != hipSuccess) return DTF_ERR_LAUNCH;
-    if (hipMemsetAsync(d->gb2, 0, sizeof(float) * C, stream) != hipSuccess) return DTF_ERR_LAUNCH;
-    if (hipMemsetAsync(d->gb1, 0, sizeof(float) * H, stream) != hipSuccess) return DTF_ERR_LAUNCH;
+    if (dtf_launch_zero(d->gW2, (long)H * C, stream) || dtf_launch_zero(d->gb2, C, stream) ||
+        dtf_launch_zero(d->gb1, H, stream))
+      return DTF_ERR_LAUNCH;
   }
   DtfHeadLaunch h;
   h.zin = d->z2;

@@ -1607,6 +1607,18 @@ extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block
 // {start, end} wall-clock stamps of the next two-launch steps; null disables.
 extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }
 
+__global__ void zero_floats_kernel(float* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// Zero-fill as a kernel launch: safe inside stream captures (see dtf_mlp_chunk_pipelined).
+int dtf_launch_zero(float* p, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  const int blocks = (int)((n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64);
+  hipLaunchKernelGGL(zero_floats_kernel, dim3(blocks), dim3(1024), 0, stream, p, (int)n);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
 // n consecutive fused steps starting at mini-batch `first_batch`, ONE launch per step (plus one
 // stand-alone forward for the first step): see step_pipe_kernel.  The chunk must stay inside one
 // epoch of the resident set, whose Gram blocks q->gram describe.
@@ -1632,7 +1644,9 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
   const Set canon{d->W1, d->b1, d->W2, d->b2}, twin{q->tW1, q->tb1, q->tW2, q->tb2};
   float* a2buf[2] = {d->z2, q->a2b};
   float* zw[3] = {q->zws3, q->zws3 + 2048, q->zws3 + 4096};
-  if (hipMemsetAsync(q->zws3, 0, sizeof(float) * 3 * 2048, stream) != hipSuccess) return DTF_ERR_LAUNCH;
+  // (a kernel, not hipMemsetAsync: inside a stream capture the memset was observed to take effect at
+  // capture time only — later replays of the graph then started from a dirty accumulator)
+  hipLaunchKernelGGL(zero_floats_kernel, dim3(6), dim3(1024), 0, stream, q->zws3, 3 * 2048);
   // The last step has to leave the parameters in the caller's tensors, so an odd chunk starts
   // from the twin set (a copy of the same values).
   const bool start_twin = (n & 1) != 0;

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kBlock) void sgd_apply_kernel(float* __restrict__ p
       p[t] -= a * g[t];
       if (zero_grad) g[t] = 0.f;
     }
-    if (threadIdx.x == 0 && global_step) *global_step = *global_step + 1.0f;
+    // atomic: several workers (processes) may apply to the same shard concurrently — the lock-free
+    // asynchronous mode — and every applied gradient has to count
+    if (threadIdx.x == 0 && global_step) atomicAdd(global_step, 1.0f);
   }
 }
 

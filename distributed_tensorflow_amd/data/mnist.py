@@ -302,11 +302,18 @@ class DeviceDataset:
             return
         if getattr(self, "_pinned", None) is None:      # two pinned staging buffers, used alternately
             self._pinned = [torch.empty(self.num_examples, dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._pin_copied = [None, None]
             self._pin_turn = 0
-        host = self._pinned[self._pin_turn]
+        turn = self._pin_turn
         self._pin_turn ^= 1
+        host = self._pinned[turn]
+        if self._pin_copied[turn] is not None:
+            # the host may run epochs ahead of the device: do not overwrite a permutation whose copy is still queued
+            self._pin_copied[turn].synchronize()
         torch.randperm(self.num_examples, generator=self._gen, out=host)
         self._staged_perm = host.to(self.device, non_blocking=True)
+        self._pin_copied[turn] = torch.cuda.Event()
+        self._pin_copied[turn].record(torch.cuda.current_stream(self.device))
 
     def _fill_gram(self, s):
         nb, b = self.batches_per_epoch, self.batch_size

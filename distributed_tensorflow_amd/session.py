@@ -150,6 +150,9 @@ class Session:
         self.fused_steps = 0
         self._local_step_ready = False
         self.generic_steps = 0
+        # host mirror of global_step for a local session (None: unknown, re-read from the device): saves one
+        # blocking device-to-host copy per sess.run that fetches it next to a train op
+        self._gs_mirror: Optional[int] = None
         if self.config.log_device_placement:
             self._log_placement()
 
@@ -212,12 +215,18 @@ class Session:
 
     # -- variables ------------------------------------------------------------------
     def var_tensor(self, v: G.Variable) -> torch.Tensor:
+        self._gs_mirror = None      # the caller may write through the view (Saver.restore, assign)
+        return self.layout.view(self.theta, v.op_name)
+
+    def _var_view(self, v: G.Variable) -> torch.Tensor:
+        """Read-only use inside the session: does not invalidate the host mirror."""
         return self.layout.view(self.theta, v.op_name)
 
     def _pull(self):
         self.store.pull(self.theta)
 
     def _run_init(self, variables: Sequence[G.Variable]):
+        self._gs_mirror = None
         seed = self.graph.seed if self.graph.seed is not None else int(time.time())
         all_vars = len(variables) == len(self.graph.variables)
         self.store.initialize(seed, None if all_vars else [v.op_name for v in variables])
@@ -240,13 +249,24 @@ class Session:
         # train ops first: they define the forward pass the other fetches see.  Variables fetched
         # in the same call (global_step) are read BEFORE the update — the reference prints
         # step+1 for that reason (tfdist_between.py:102).
-        if any(_is(f, "train") for f in flist):
+        trains = [f for f in flist if _is(f, "train")]
+        if trains:
+            gs_var = trains[0].attrs["global_step"] if len(trains) == 1 else None
+            mirror_ok = gs_var is not None and not self.store.is_remote
             for f in flist:
                 if _is(f, "variable"):
-                    cache[f] = self.var_tensor(f).clone()
-        for f in flist:
-            if _is(f, "train"):
-                self._run_train(f, feed, cache)
+                    if mirror_ok and f is gs_var:
+                        if self._gs_mirror is None:
+                            self._gs_mirror = int(round(float(self._var_view(f).item())))
+                        cache[f] = torch.tensor(float(self._gs_mirror))         # host value, pre-update
+                    else:
+                        cache[f] = self._var_view(f).clone()
+            if not mirror_ok:
+                self._gs_mirror = None
+        for f in trains:
+            self._run_train(f, feed, cache)
+            if self._gs_mirror is not None:
+                self._gs_mirror += 1
         out = []
         for f in flist:
             out.append(self._fetch(f, feed, cache))
@@ -309,7 +329,7 @@ class Session:
         ins = node.inputs
         ev = lambda n: self._eval(n, feed, cache, var_override)  # noqa: E731
         if op == "variable":
-            r = var_override[node] if (var_override and node in var_override) else self.var_tensor(node)
+            r = var_override[node] if (var_override and node in var_override) else self._var_view(node)
         elif op == "placeholder":
             r = self._feed_tensor(node, feed)
         elif op == "const":
@@ -410,7 +430,7 @@ class Session:
             r = dst
         elif op == "gradient":
             loss, var = ins[0], node.attrs["wrt"]
-            leaf = self.var_tensor(var).detach().clone().requires_grad_(True)
+            leaf = self._var_view(var).detach().clone().requires_grad_(True)
             val = self._eval(loss, feed, {}, {var: leaf})
             (r,) = torch.autograd.grad(val, [leaf], allow_unused=True)
             if r is None:
@@ -429,6 +449,9 @@ class Session:
             params = {r: self.layout.view(self.theta, n) for r, n in names.items()}
             grads = {r: self.layout.view(self.grad, n) for r, n in names.items()}
             eng = MLPEngine(params, grads, batch=batch, lr=0.0, act=m["act"], hist_cap=1)
+            # loss and batch accuracy side by side: ONE 8-byte device-to-host copy per step
+            eng._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+            eng.loss_hist, eng.acc_hist = eng._stats[0:1], eng._stats[1:2]
             K, C = params["W1"].shape[0], params["W2"].shape[1]
             eng._x_stage = torch.zeros((batch, K), dtype=torch.float32, device=self.device)
             eng._y_stage = torch.zeros((batch, C), dtype=torch.float32, device=self.device)
@@ -471,15 +494,16 @@ class Session:
             eng = self._engine_for(m, batch)
             self._stage(eng, m, feed)
             eng.step_grad(0, 1.0)
-            cache[m["loss"]] = eng.loss_hist[0].clone()
-            cache[("acc", id(m["loss"]))] = eng.acc_hist[0].clone()
+            host = eng._stats.cpu()          # the step's only wait for the device
+            cache[m["loss"]] = host[0]
+            cache[("acc", id(m["loss"]))] = host[1]
             for n in plan["acc_nodes"]:
                 cache[n] = cache[("acc", id(m["loss"]))]
             self.fused_steps += 1
         else:
             self.grad.zero_()
             var_list = train_op.attrs["var_list"]
-            leaves = {v: self.var_tensor(v).detach().clone().requires_grad_(True) for v in var_list}
+            leaves = {v: self._var_view(v).detach().clone().requires_grad_(True) for v in var_list}
             fcache: Dict[G.Tensor, Any] = {}
             loss_val = self._eval(train_op.attrs["loss"], feed, fcache, leaves)
             grads = torch.autograd.grad(loss_val, [leaves[v] for v in var_list], allow_unused=True)

@@ -234,3 +234,22 @@ def test_pipelined_chunk_graph_replay_and_two_launch_agree():
     for k in MLPEngine.PARAM_NAMES:
         torch.testing.assert_close(a.p[k], b.p[k], rtol=2e-4, atol=2e-5)
     assert a._host_cursor == 11 and float(a.global_step) == 11.0
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5])
+def test_pipelined_graphs_can_be_replayed_in_any_order(n):
+    """A chunk graph must not depend on what the previous chunk left in the work buffers (logit accumulators,
+    twin parameters): replay two graphs alternately and compare every replay with the eager chunk."""
+    g = _engine(DEV, with_grads=False, nb=30)
+    e = _engine(DEV, with_grads=False, nb=30)
+    for t in (g, e):
+        t.bind_gram(_pair_gram(t))
+    for pos in (7, 0, 7, 0, 7):
+        g.set_cursor(pos)
+        e.set_cursor(pos)
+        g.run_chunk(n, use_graph=True)
+        e.run_chunk(n, use_graph=False)
+        torch.cuda.synchronize()
+        for k in MLPEngine.PARAM_NAMES:
+            torch.testing.assert_close(g.p[k], e.p[k], rtol=1e-5, atol=1e-6)
+            g.p[k].copy_(e.p[k])
