@@ -1,36 +1,33 @@
-// Two-launch training step for small batches (B <= 128, H <= 128, C <= 16):
+// Training step of the small-batch MLP (B <= 128, H <= 128, C <= 16) in TWO launches or in ONE.
 //
-//   launch 1  fwd_tile16   a2 = act(x W1 + b1)                      (F1-F3)
-//   launch 2  bwd_all      logits, softmax-xent, accuracy, dz3, dW2, db2,
-//                          dz2, db1, dW1 and (optionally) the SGD update
-//                                                                   (F4-F12, G1-G7, U1-U2)
+//   two launches (gradient modes: PS transports, collectives; also the fused fallback)
+//     launch 1  fwd_tile8 / fwd_tile16   a2 = act(x W1 + b1), logit partials      (F1-F3, part of F4)
+//     launch 2  bwd_tile16               logits, softmax-xent, accuracy, dz3, dW2, db2, dz2, db1, dW1
+//                                        and (fused mode) the SGD update          (F4-F12, G1-G7, U1-U2)
+//   one launch per step (fused single-GPU training; dtf_mlp_chunk_pipelined)
+//     step_pipe                          launch 2 of step t ++ launch 1 of step t+1, see its comment
 // (op numbers: the reference graph, tfdist_between.py:55-70).
 //
-// Why this shape.  A kernel boundary on MI355X costs ~1.5 us and one CU retires
-// only ~128 fp32 lanes per clock, so at batch 100 both the NUMBER of launches and
-// any work funnelled through a single workgroup dominate the step:
-//   * the forward GEMM is tiled 16x16 (49 workgroups for 100x100) with the K
-//     dimension split over the 16 waves of the workgroup and reduced in LDS —
-//     no inter-workgroup atomics, deterministic, and the bias + activation are
-//     spread over 49 CUs instead of one;
-//   * a CU ingests only ~40-60 GB/s on a latency-bound stream, so no workgroup
-//     may load more than a few tens of KB: the forward workgroups add their
-//     share of the LOGITS (a [16 x 10] partial product) into a 6 KB accumulator
-//     with f32 atomics, and every backward workgroup redoes the softmax /
-//     cross-entropy gradient for the whole batch from those 6 KB instead of
-//     waiting for a single-workgroup head kernel and another boundary;
-//   * dz2 is never materialised — it is formed in registers as the B operand of
-//     the dW1 MFMA:  dz2[m][h] = act'(a2[m][h]) * sum_c dz3[m][c] W2[h][c]
-//   * dW2 tiles, db2, db1 and the step statistics are "duties" dealt to the
-//     first workgroups of the same launch.
-// Each kernel makes ONE global-memory round trip: all loads are issued before
-// the first one is consumed.
+// Why this shape.  A kernel boundary on MI355X costs 1.5-2 us, one CU retires only ~128 fp32 lanes per
+// clock and pulls only ~40-60 GB/s from cold caches, so at batch 100 the NUMBER of launches, any work
+// funnelled through a single workgroup and the BYTES per workgroup dominate the step:
+//   * small tiles on many CUs: forward 8x8 (169 workgroups for 100x100; two k ranges share one
+//     16x16x4 MFMA on its diagonal), backward 32x16 (175 + 7 + 1 workgroups); the K dimension (forward)
+//     and the batch (backward) are split over the waves of a workgroup and reduced in LDS;
+//   * the forward workgroups add their share of the LOGITS (an [8 x 10] partial product) into a 6 KB
+//     accumulator with f32 atomics, and every backward workgroup redoes the softmax / cross-entropy
+//     gradient for the whole batch from those 6 KB instead of waiting for a single-workgroup head
+//     kernel and another boundary;
+//   * dz2 is never materialised — it is formed in registers as the B operand of the dW1 MFMA:
+//     dz2[m][h] = act'(a2[m][h]) * sum_c dz3[m][c] W2[h][c];
+//   * dW2 tiles, db2 and the step statistics are dedicated workgroups of the same launch;
+//   * every kernel makes ONE global-memory round trip: straight-line code, all byte offsets computed
+//     first, all loads issued back to back in a pinned order, counted waits where the values are used.
 //
-// In-place SGD and the W2 race: the backward launch reads W2/b2 in every
-// workgroup and (fused mode) also writes them.  Workgroups of one launch are
-// not ordered, so the readers use a SHADOW copy of W2/b2 that workgroup 0 of
-// the forward launch refreshes from the live parameters (the forward pass does
-// not read W2).  Live parameters are therefore always current.
+// In-place SGD and the W2 race (two-launch fused mode): the backward launch reads W2/b2 in every
+// workgroup and also writes them.  Workgroups of one launch are not ordered, so the readers use a SHADOW
+// copy of W2/b2 that the forward launch refreshes from the live parameters (the forward pass reads W2
+// only for the logit partials, before the update).  Live parameters are therefore always current.
 #include "dtf_api.h"
 #include "dtf_internal.h"
 
@@ -234,127 +231,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   DTF_BLOCK_STAMP(bs, 1);
 }
 
-// Specialisation for the common shape (K % 4 == 0, K - 256*NMS in [0, 64], H*C + C <= 1024;
-// the reference's 784-100-10 has NMS = 3): straight-line code, ONE memory round trip.
-//   * wave w contracts the full macro-steps w, w+16, ... (NMS of them, none wasted) and ONE
-//     4-wide tail step k = 256*NMS + 4w + q, instead of ceil(K/256) partly empty macro-steps;
-//   * every byte offset is computed before the first load, and the loads are issued back to
-//     back in a pinned order (contraction operands first, epilogue operands last).  In the
-//     generic kernel above the loop header and the vector/scalar load paths make the compiler
-//     wait for earlier loads between macro-steps, i.e. several dependent round trips;
-//   * workgroup 0's extra duties (shadow copy of W2/b2, clearing the other logit accumulator)
-//     take their operands in the same load sequence and store at the very end.
-template <int NMS>
-__global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_fast_kernel(
-    const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
-    const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
-    float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
-    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
-  DTF_BLOCK_STAMP(bs, 0);
-  __shared__ float red[kFwdWaves][4][64];
-  __shared__ float a2t[16][17];
-  __shared__ float w2t[64][17];   // rows >= 16 are written (never read) so that the W2 load is used by every thread
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i16 = lane & 15, q = lane >> 4;
-  const int tn = blockIdx.x, tm = blockIdx.y;     // 2-D grid: no integer division on the way to the first load
-  const int m0 = tm * 16, n0 = tn * 16;
-  const float* __restrict__ X = xbase + batch_index * (long)M * (long)K;
-  const int row = m0 + i16, col = n0 + i16;
-  const bool col_ok = col < H;
-  const unsigned row_c = row < M ? row : M - 1, col_c = col_ok ? col : H - 1;
-
-  // ---- offsets (bytes), all before the first load -------------------------------------------
-  unsigned xo[NMS], wo[NMS][4];
-#pragma unroll
-  for (int j = 0; j < NMS; ++j) {
-    const unsigned kb = (wave + j * kFwdWaves) * 16 + q * 4;     // < 256*NMS <= K: always inside
-    xo[j] = (row_c * K + kb) * 4u;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wo[j][s] = ((kb + s) * H + col_c) * 4u;
-  }
-  const unsigned kt = 256u * NMS + 4u * wave + q;                 // tail step: one k per lane quarter
-  const bool kt_ok = kt < (unsigned)K;
-  const unsigned ktc = kt_ok ? kt : K - 1;
-  const unsigned xto = (row_c * K + ktc) * 4u, wto = (ktc * H + col_c) * 4u;
-  // epilogue operands (threads < 256 own one tile element each)
-  const int e_reg = threadIdx.x >> 6, e_lane = threadIdx.x & 63;
-  const int e_col = n0 + (e_lane & 15);
-  const unsigned bo = umin_(col, H - 1) * 4u;     // bias of this lane's column: added to wave 0's partial
-  const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;          // threads < 256: W2 tile element
-  const bool w2_ok = n0 + w_h < H && w_c < C;
-  const unsigned w2o = umin_((n0 + w_h) * C + w_c, (unsigned)H * C - 1) * 4u;
-  // shadow element of this thread (stored by workgroup 0 only): W2 flat, then b2
-  const unsigned se = threadIdx.x, hc = (unsigned)H * C;
-  const bool s_in_w2 = se < hc;
-  const unsigned sow = umin_(se, hc - 1) * 4u, sob = umin_(se - hc, C - 1) * 4u;   // se < hc wraps: clamped
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- loads, back to back ------------------------------------------------------------------
-  f32x4 a[NMS];
-  float bv[NMS][4];
-#pragma unroll
-  for (int j = 0; j < NMS; ++j) {
-    a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + xo[j]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(W, wo[j][s]);
-  }
-  const float at = ld_ub(X, xto);
-  const float bt_raw = ld_ub(W, wto);
-  __builtin_amdgcn_sched_barrier(0);
-  const float bias = ld_ub(b, bo);
-  const float w2raw = ld_ub(W2, w2o);
-  const float sh_w = ld_ub(W2, sow);
-  const float sh_b = ld_ub(b2, sob);
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- contraction: columns beyond H and the tail beyond K are masked in B ----------------------
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < NMS; ++j) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], col_ok ? bv[j][0] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], col_ok ? bv[j][1] : 0.f, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], col_ok ? bv[j][2] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], col_ok ? bv[j][3] : 0.f, acc1, 0, 0, 0);
-  }
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at, (col_ok && kt_ok) ? bt_raw : 0.f, acc0, 0, 0, 0);
-  // The bias rides on wave 0's partial sums, so every thread consumes its load here (a load used
-  // only inside the `threadIdx.x < 256` epilogue is sunk there by the compiler: a second round trip).
-  const f32x4 acc = acc0 + acc1;
-  const float badd = wave == 0 ? bias : 0.f;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) red[wave][g][lane] = acc[g] + badd;
-  w2t[w_h][w_c] = w2_ok ? w2raw : 0.f;
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < kFwdWaves; ++w) s += red[w][e_reg][e_lane];
-    const int lrow = 4 * (e_lane >> 4) + e_reg;
-    const int orow = m0 + lrow;
-    float av = 0.f;
-    if (orow < M && e_col < H) {
-      av = fast_act(s, act);
-      out[(long)orow * H + e_col] = av;
-    }
-    a2t[lrow][e_lane & 15] = av;
-  }
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    const int lrow = threadIdx.x >> 4, c = threadIdx.x & 15;
-    if (m0 + lrow < M && c < C) {
-      float z = 0.f;
-#pragma unroll
-      for (int h = 0; h < 16; ++h) z += a2t[lrow][h] * w2t[h][c];
-      atomicAdd(&zacc[(m0 + lrow) * 16 + c], z);
-    }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
-    if (shadow_dst && se < hc + C) shadow_dst[se] = s_in_w2 ? sh_w : sh_b;
-    for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
-  }
-  DTF_BLOCK_STAMP(bs, 1);
-}
-
 // Forward with 8x8 output tiles: twice the workgroups in each direction (13 x 13 = 169 for
 // 100 x 100), each ingesting half as many rows of x and half as many columns of W: 2 x 25 KB
 // instead of 2 x 50 KB.  A CU ingests a cold stream at only 40-60 GB/s, so the bytes per
@@ -535,321 +411,7 @@ struct BwdParams {
     }                                                                          \
   } while (0)
 
-// Grid = [main blocks: one 32x32 tile of dW1 each] ++ [duty blocks: one 32-row tile of dW2
-// each, then one block for db2 + step statistics].  Duty blocks run beside the main blocks
-// instead of lengthening some of them.  Every block first rebuilds dz3 for the whole batch
-// from the 6 KB logit accumulator with four threads per batch row.
-//
-// A dW2 duty block is the main code path with other operands: both are X^T * G products
-// contracted over the batch with 32x32x2 MFMAs, eight waves splitting the batch-row pairs,
-//     main   dW1[k0+i][h0+j] = sum_m x[m][k0+i]  * dz2[m][h0+j]      (dz2 formed in registers)
-//     duty   dW2[h0+i][c=j]  = sum_m a2[m][h0+i] * dz3[m][j]         (dz3 read from LDS)
-// so every block executes the SAME straight-line sequence of global loads (the roles differ
-// only in tile origin; operands a role does not use are valid, harmless reads).  Role-specific
-// loads in separate branches make the compiler drain the memory counter where the branches
-// meet, i.e. a full memory round trip in the middle of the issue phase.
 constexpr int kLdz = 20;   // dz3s row stride: 16-B aligned rows (broadcast b128 reads)
-
-// NJ = batch-row pairs per wave (ceil(ceil(M/2)/8)), CQ = class quads contracted per dz2 element
-// (ceil(C/4)).  Both are compile-time so that the contraction loop is straight-line code: the
-// LDS reads, dot products and MFMAs of different steps overlap instead of running one at a time.
-template <int NJ, int CQ>
-__global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
-  static_assert(NJ >= 1 && NJ <= 8 && CQ >= 1 && CQ <= 4, "operand slots");
-  __shared__ __attribute__((aligned(16))) float smem[8192 + 128 * kLdz + 32 * kLdw + 256 + 64];
-  float* red = smem;                         // [8][16][64] partial tiles (phase 2+)
-  float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
-  float* ys = smem + 128 * kLdw;             // [128][17] labels    (phase 1, aliases red)
-  float* dz3s = smem + 8192;                 // [128][kLdz]; rows >= M are zero
-  float* w2t = dz3s + 128 * kLdz;            // [32][17] W2 rows of this h tile (zero beyond H / C)
-  float* rowstat = w2t + 32 * kLdw;          // [2][128] per-row loss / correct flag (statistics block)
-  float* b2s = rowstat + 256;                // [16]
-  float* db2s = b2s + 16;                    // [16]
-  float* scal = db2s + 16;                   // [0] loss sum, [1] correct count
-
-  const int R = p.R, H = p.H, C = p.C, M = p.M, K = p.K;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r32 = lane & 31, half = lane >> 5;
-  // 2-D grid (no integer division): x = h tile; y < tiles_k: dW1 tile row y; y == tiles_k: dW2
-  // tile x; y == tiles_k + 1: the statistics block (x == 0; its tile loads are unused).
-  const int tiles_k = (K + 31) >> 5;
-  const bool is_main = (int)blockIdx.y < tiles_k;
-  const bool stats_block = (int)blockIdx.y == tiles_k + 1;
-  if (stats_block && blockIdx.x != 0) return;
-  const int th = blockIdx.x, tk = is_main ? (int)blockIdx.y : 0;
-  const int k0 = tk * 32, h0 = th * 32;
-
-  DTF_BLOCK_STAMP(p.bs, 0);
-  DTF_STAMP2(0);
-  // ---- phase 0: issue every global load -------------------------------------
-  const float* __restrict__ X = p.xbase + p.batch_index * (long)M * (long)K;
-  const float* __restrict__ Y = p.ybase + p.batch_index * (long)M * (long)C;
-  const float lr = *p.lr;   // always a valid pointer (checked by the launcher): no branch before the loads
-
-  // Every index below is a 32-bit offset clamped into its buffer with one v_min; values are
-  // masked where they are consumed (or need no mask at all), so the whole batch of loads is in
-  // flight before the first wait.
-  // logits + labels, flat [row][16] image: thread element e = tid + u*512 (the accumulator holds
-  // 2048 floats, rows >= M are zero: no clamp needed)
-  //
-  // All byte offsets are computed BEFORE the first load is issued and the order of the loads is
-  // pinned: (1) what phase 1 stages (logits, labels, b2, W2 tile), (2) the contraction operands,
-  // (3) the old values of the outputs.  Loads retire in order, so phase 1 waits only for group 1
-  // while groups 2 and 3 stay in flight behind the softmax.  (Left to itself the scheduler
-  // interleaves address arithmetic with the loads, reuses registers of loads in flight for it and
-  // then has to wait for those loads in the middle of the issue phase.)
-  // Offsets use 24-bit multiplies (one v_mad_u32_u24 each; every index is far below 2^24): a
-  // generic 32-bit multiply-add becomes a 64-bit mad whose unused high half the register
-  // allocator may place on a load still in flight, which costs a wait in the issue phase.
-  const unsigned y_max = (unsigned)M * C - 1;
-  unsigned yo[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned e = tid + u * kBwdThreads;
-    yo[u] = umin_(__umul24(e >> 4, C) + (e & 15), y_max) * 4u;
-  }
-  const unsigned b2o = umin_(tid, C - 1) * 4u;
-  const unsigned w2o = umin_(__umul24(h0 + (tid >> 4), C) + (tid & 15), (unsigned)H * C - 1) * 4u;
-  __builtin_amdgcn_sched_barrier(0);
-  float zreg[4], yreg[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    zreg[u] = ld_u(p.zacc, tid + u * kBwdThreads);
-    yreg[u] = ld_ub(Y, yo[u]);                                   // masked when staged into LDS
-  }
-  const float b2raw = ld_ub(p.b2r, b2o);
-  // W2 rows of the h tile [32][16]: dz2 operand (main), old values of the output tile (duty)
-  const float w2reg = ld_ub(p.W2r, w2o);
-  __builtin_amdgcn_sched_barrier(0);
-
-  // x and a2 operands stay unmasked: rows >= M meet dz3 == 0 and columns >= H meet W2 == 0, so
-  // the products are 0 there whatever (finite) value was read; tile rows beyond the output
-  // matrix are never stored.  Byte offsets advance by a constant per step: add + min per load.
-  const unsigned kc = umin_(k0 + r32, K - 1), hc = umin_(h0 + r32, H - 1);
-  const unsigned x_max4 = (__umul24(M - 1, K) + kc) * 4u, a_max4 = (__umul24(M - 1, H) + hc) * 4u;
-  const unsigned m0r = 2 * wave + half;
-  const unsigned x_base4 = (__umul24(m0r, K) + kc) * 4u, a_base4 = (__umul24(m0r, H) + hc) * 4u;
-  const unsigned x_step4 = 8u * kBwdWaves * K, a_step4 = 8u * kBwdWaves * H;      // 2*waves rows, in bytes
-  unsigned xo[NJ], ao[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    xo[j] = umin_(x_base4 + j * x_step4, x_max4);
-    ao[j] = umin_(a_base4 + j * a_step4, a_max4);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  float xreg[NJ], areg[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    xreg[j] = ld_ub(X, xo[j]);
-    areg[j] = ld_ub(p.a2, ao[j]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // fused mode reads the old weights; in gradient mode the same (valid) locations of the
-  // gradient slab are read and ignored, which keeps the loads free of control flow
-  const unsigned w_max = (unsigned)K * H - 1;
-  unsigned wo[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + j * kBwdThreads;
-    const int g = e >> 6, l = e & 63;
-    const unsigned orow = k0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
-    const unsigned ocol = h0 + (l & 31);
-    wo[j] = umin_(__umul24(orow, H) + ocol, w_max) * 4u;
-  }
-  const unsigned b1o = umin_(h0 + (tid & 31), H - 1) * 4u;
-  __builtin_amdgcn_sched_barrier(0);
-  float wold[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) wold[j] = ld_ub(p.oW1, wo[j]);
-  const float b1old = ld_ub(p.ob1, b1o);
-  __builtin_amdgcn_sched_barrier(0);
-
-  DTF_STAMP2(1);
-  // ---- phase 1: stage logits/labels, then softmax-xent ----------------------------------------
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + u * kBwdThreads;       // all 128 rows are staged: rows >= M as zeros
-    const bool ok = (e >> 4) < M && (e & 15) < C;
-    zs[(e >> 4) * kLdw + (e & 15)] = ok ? zreg[u] : 0.f;
-    ys[(e >> 4) * kLdw + (e & 15)] = ok ? yreg[u] : 0.f;
-  }
-  w2t[(tid >> 4) * kLdw + (tid & 15)] = (h0 + (tid >> 4) < H && (tid & 15) < C) ? w2reg : 0.f;
-  if (tid < 16) {
-    b2s[tid] = tid < C ? b2raw : 0.f;
-    db2s[tid] = 0.f;
-  }
-  __syncthreads();
-  const float inv_batch = 1.0f / (float)M;
-  {
-    // four threads per batch row, four classes each; row reductions are two quad-DPP steps
-    const int row = tid >> 2, part = tid & 3;      // 128 rows: every row of dz3s is written
-    const bool row_ok = row < M;
-    float z[4], y[4], ex[4];
-    float mx = -INFINITY, ysum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = 4 * part + i;
-      z[i] = zs[row * kLdw + c] + b2s[c];
-      y[i] = ys[row * kLdw + c];
-      mx = fmaxf(mx, c < C ? z[i] : -INFINITY);
-      ysum += y[i];                                   // zero beyond C
-    }
-    mx = fmaxf(mx, dpp_f<kXor1>(mx));
-    mx = fmaxf(mx, dpp_f<kXor2>(mx));
-    ysum += dpp_f<kXor1>(ysum);
-    ysum += dpp_f<kXor2>(ysum);
-    float se = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ex[i] = (4 * part + i < C) ? fast_exp(z[i] - mx) : 0.f;
-      se += ex[i];
-    }
-    se += dpp_f<kXor1>(se);
-    se += dpp_f<kXor2>(se);
-    const float inv = fast_rcp(se) * ysum;
-    f32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      out[i] = (row_ok && 4 * part + i < C) ? (ex[i] * inv - y[i]) * inv_batch : 0.f;
-    *reinterpret_cast<f32x4*>(dz3s + row * kLdz + 4 * part) = out;
-    if (stats_block) {   // block-uniform
-      const float lse = mx + fast_log(se);
-      float rloss = 0.f, bz = -INFINITY, by = -INFINITY;
-      int az = 0, ay = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = 4 * part + i;
-        if (c < C) {
-          rloss -= y[i] * (z[i] - lse);
-          if (z[i] > bz) { bz = z[i]; az = c; }     // strict > keeps the smallest index on ties
-          if (y[i] > by) { by = y[i]; ay = c; }
-        }
-      }
-      rloss += dpp_f<kXor1>(rloss);
-      rloss += dpp_f<kXor2>(rloss);
-      argmax_step<kXor1>(bz, az);
-      argmax_step<kXor2>(bz, az);
-      argmax_step<kXor1>(by, ay);
-      argmax_step<kXor2>(by, ay);
-      if (part == 0) {
-        rowstat[row] = row_ok ? rloss : 0.f;
-        rowstat[128 + row] = (row_ok && az == ay) ? 1.f : 0.f;
-      }
-    }
-  }
-  __syncthreads();
-  DTF_STAMP2(2);
-  const float gs = p.grad_scale;
-
-  if (!stats_block) {
-    // ---- phase 2: the 32x32 output tile.  Steps beyond the batch need no mask: their dz3 rows
-    // are zero, so both kinds of B operand are exactly 0 there.
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float db1part = 0.f;
-    if (is_main) {
-      float w2row[4 * CQ];
-#pragma unroll
-      for (int c = 0; c < 4 * CQ; ++c) w2row[c] = w2t[r32 * kLdw + c];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int m = 2 * (wave + j * kBwdWaves) + half;            // <= 127
-        const f32x4* d4 = reinterpret_cast<const f32x4*>(dz3s + m * kLdz);   // broadcast reads
-        float part[CQ];
-#pragma unroll
-        for (int qd = 0; qd < CQ; ++qd) {       // independent partial sums: short dependency chains
-          const f32x4 d = d4[qd];
-          part[qd] = d[0] * w2row[4 * qd] + d[1] * w2row[4 * qd + 1] + d[2] * w2row[4 * qd + 2] +
-                     d[3] * w2row[4 * qd + 3];
-        }
-        float da = part[0];
-#pragma unroll
-        for (int qd = 1; qd < CQ; ++qd) da += part[qd];
-        const float dz2 = da * dtf_act_bwd(areg[j], p.act);
-        db1part += dz2;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xreg[j], dz2, acc, 0, 0, 0);
-      }
-    } else {
-      const int cc = r32 < 16 ? r32 : 0;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int m = 2 * (wave + j * kBwdWaves) + half;
-        const float d = dz3s[m * kLdz + cc];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], r32 < 16 ? d : 0.f, acc, 0, 0, 0);
-      }
-    }
-    DTF_STAMP2(3);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) red[(wave * 16 + g) * 64 + lane] = acc[g];
-    __syncthreads();
-    DTF_STAMP2(4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = tid + j * kBwdThreads;
-      const int g = e >> 6, l = e & 63;
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 16 + g) * 64 + l];
-      const int trow = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), tcol = l & 31;
-      if (is_main) {
-        const int orow = k0 + trow, ocol = h0 + tcol;
-        if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[j] - lr * s : gs * s;
-      } else {
-        const int h = h0 + trow;
-        if (h < H && tcol < C) p.oW2[h * C + tcol] = p.fused ? w2t[trow * kLdw + tcol] - lr * s : gs * s;
-      }
-    }
-    DTF_STAMP2(5);
-    // db1: the workgroups of k-tile 0 see every batch row of their 32 columns
-    if (is_main && tk == 0) {
-      __syncthreads();   // red is reused
-      db1part += __shfl_xor(db1part, 32);
-      if (lane < 32) red[wave * 32 + lane] = db1part;
-      __syncthreads();
-      if (tid < 32 && h0 + tid < H) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[w * 32 + tid];
-        p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
-      }
-    }
-    DTF_STAMP2(6);
-  } else {
-    // ---- duty: db2 and the step statistics -------------------------------------------------
-    DTF_STAMP2(3);
-    {
-      const int c = tid & 15, part = tid >> 4;      // 32 row groups x 16 classes
-      float s = 0.f;
-      for (int r = part; r < R; r += kBwdThreads / 16) s += dz3s[r * kLdz + c];
-      atomicAdd(&db2s[c], s);
-    }
-    if (wave == 0) {   // sum the per-row loss / correct flags: 2 values per lane, then a wave reduction
-      float l = rowstat[lane] + rowstat[lane + 64];
-      float k = rowstat[128 + lane] + rowstat[128 + lane + 64];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        l += __shfl_xor(l, m);
-        k += __shfl_xor(k, m);
-      }
-      if (lane == 0) {
-        scal[0] = l;
-        scal[1] = k;
-      }
-    }
-    __syncthreads();
-    DTF_STAMP2(4);
-    if (tid < C) p.ob2[tid] = p.fused ? b2s[tid] - lr * db2s[tid] : gs * db2s[tid];
-    if (tid == 0) {
-      if (p.loss_hist) p.loss_hist[p.hist_slot] = scal[0] * inv_batch;
-      if (p.acc_hist) p.acc_hist[p.hist_slot] = scal[1] * inv_batch;
-      DTF_STAMP2(5);
-      if (p.fused && p.global_step) *p.global_step = *p.global_step + 1.0f;
-      DTF_STAMP2(6);
-    }
-  }
-  DTF_STAMP2(7);
-  DTF_BLOCK_STAMP(p.bs, 1);
-}
 
 // Backward with 32(k) x 16(h) tiles of dW1: 175 + 7 + 1 workgroups instead of 100 + 4 + 1, each
 // ingesting ~40 KB instead of ~55 KB (same reasoning as the 8x8 forward tiling: the bytes a CU
@@ -857,9 +419,15 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_all_kernel(BwdParams p) {
 // (i = l & 15, q = l >> 4), wave w contracts batch-row quads w, w+8, ... (row m = 4 quad + q):
 //     main   dW1[k0+16s+i][h0+j] = sum_m x[m][k0+16s+i] * dz2[m][h0+j]     (s = 0, 1: two A tiles, one B)
 //     duty   dW2[h0+i][c=j]      = sum_m a2[m][h0+i]    * dz3[m][j]
-// The a2 operand has the same lane mapping in both roles, so — as in bwd_all_kernel — every
-// block executes one straight-line sequence of loads.  dz2 is formed once per (row, column)
-// and feeds both MFMAs: half the dot products of the 32x32 tiling.
+// The a2 operand has the same lane mapping in both roles, so every block executes ONE straight-line
+// sequence of loads: role-specific loads in separate branches make the compiler drain the memory
+// counter where the branches meet, a full memory round trip in the middle of the issue phase.
+// dz2 is formed once per (row, column) and feeds both MFMAs.
+//
+// Grid = [dW1 tiles] ++ [one row of dW2 tiles] ++ [one block for db2 + step statistics]; the extra
+// duties run beside the tiles instead of lengthening some of them.  Every block first rebuilds dz3 for
+// the whole batch from the 6 KB logit accumulator with four threads per batch row.
+
 // Softmax inputs straight into registers: thread (row = tid >> 2, part = tid & 3) owns classes
 // 4 part .. 4 part + 3 of batch row `row` — the logits as ONE 16-byte load (the accumulator is a
 // [128][16] image, always in bounds), labels and output bias clamped into their buffers and masked at
@@ -1479,7 +1047,6 @@ __global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp, i
   bwd_tile16_body<4, CQ, kPipeNA, YV2>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
 }
 
-bool g_bwd_tile16 = true;
 int g_pipe_parts = 3;   // timing experiments: 1 = forward tiles only, 2 = backward tiles only (results are then wrong)
 bool g_fwd_tile8 = true;
 long long* g_stamps2 = nullptr;
@@ -1508,8 +1075,6 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   float* zacc = d->zws + (parity & 1) * 2048;
   float* zother = d->zws + ((parity & 1) ^ 1) * 2048;
   const int tiles_m = (B + 15) / 16, tiles_n = (H + 15) / 16;
-  const int nms_full = K / 256, k_tail = K - 256 * nms_full;
-  const bool fast_fwd = (K & 3) == 0 && nms_full >= 1 && nms_full <= 4 && k_tail <= 64 && H * C + C <= kFwdWaves * 64;
 #define DTF_FWD_ARGS                                                                                   \
   dim3(tiles_n, tiles_m), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
@@ -1526,14 +1091,6 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
     hipLaunchKernelGGL((fwd_tile8_kernel<3>), DTF_FWD8_ARGS);
   } else if (tile8 && ns8 == 4) {
     hipLaunchKernelGGL((fwd_tile8_kernel<4>), DTF_FWD8_ARGS);
-  } else if (fast_fwd && nms_full == 3) {
-    hipLaunchKernelGGL((fwd_tile16_fast_kernel<3>), DTF_FWD_ARGS);
-  } else if (fast_fwd && nms_full == 1) {
-    hipLaunchKernelGGL((fwd_tile16_fast_kernel<1>), DTF_FWD_ARGS);
-  } else if (fast_fwd && nms_full == 2) {
-    hipLaunchKernelGGL((fwd_tile16_fast_kernel<2>), DTF_FWD_ARGS);
-  } else if (fast_fwd && nms_full == 4) {
-    hipLaunchKernelGGL((fwd_tile16_fast_kernel<4>), DTF_FWD_ARGS);
   } else {
     hipLaunchKernelGGL(fwd_tile16_kernel, DTF_FWD_ARGS);
   }
@@ -1569,25 +1126,16 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   p.stamps = g_stamps2;
   p.bs = BlockStamps{g_block_stamps ? g_block_stamps + 2 * 256 : nullptr};
   const int tiles_k = (K + 31) / 32, cq = (C + 3) / 4;
-  const int tiles_h = g_bwd_tile16 ? (H + 15) / 16 : (H + 31) / 32;
+  const int tiles_h = (H + 15) / 16;
   // linear ids: dW1 tiles, then dW2 tiles, then the statistics block (negative: counted from it backwards)
   p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h + tiles_h + 1 + g_stamp_block;
   const dim3 grid(tiles_h, tiles_k + 2), block(kBwdThreads);
-  if (g_bwd_tile16) {
-    // labels as 8-byte loads when every row pair is 8-byte aligned
-    const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
-    if (cq <= 3 && yv2) {
-      hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
-    } else {
-      hipLaunchKernelGGL((bwd_tile16_kernel<4, 4, false>), grid, block, 0, stream, p);
-    }
+  // labels as 8-byte loads when every row pair is 8-byte aligned
+  const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
+  if (cq <= 3 && yv2) {
+    hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
   } else {
-    const int nj = ((B + 1) / 2 + kBwdWaves - 1) / kBwdWaves;
-    if (nj <= 7 && cq <= 3) {          // the reference shape: batch 100, 10 classes
-      hipLaunchKernelGGL((bwd_all_kernel<7, 3>), grid, block, 0, stream, p);
-    } else {
-      hipLaunchKernelGGL((bwd_all_kernel<8, 4>), grid, block, 0, stream, p);
-    }
+    hipLaunchKernelGGL((bwd_tile16_kernel<4, 4, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
@@ -1595,8 +1143,6 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
 // Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.
 extern "C" void dtf_debug_set_fwd_tile8(int on) { g_fwd_tile8 = on != 0; }
 extern "C" void dtf_debug_set_pipe_parts(int parts) { g_pipe_parts = parts; }
-// Same for the backward launch: 32x16 tiles of dW1 (default) or 32x32 tiles.
-extern "C" void dtf_debug_set_bwd_tile16(int on) { g_bwd_tile16 = on != 0; }
 
 // Profiling hook: device buffer of >= 32 int64 receiving {wall_clock64, clock64}
 // at the phase boundaries of the LAST workgroup of bwd_all; null disables.

@@ -93,8 +93,6 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_debug_force_generic_path.restype = None
     lib.dtf_debug_set_fwd_tile8.argtypes = [i32]
     lib.dtf_debug_set_fwd_tile8.restype = None
-    lib.dtf_debug_set_bwd_tile16.argtypes = [i32]
-    lib.dtf_debug_set_bwd_tile16.restype = None
     lib.dtf_debug_set_head_stamps.argtypes = [vp]
     lib.dtf_debug_set_head_stamps.restype = None
     for name in ("dtf_mlp_step_fused", "dtf_mlp_step_grad", "dtf_advance_cursor", "dtf_mlp_eval",
@@ -297,10 +295,6 @@ def force_generic_path(on: bool):
 
 
 def set_forward_tile8(on: bool):
-    """Two-launch path: forward with 8x8 output tiles (default) or with 16x16 tiles."""
+    """Two-launch path: forward with 8x8 output tiles (default) or the generic 16x16-tile kernel."""
     require().dtf_debug_set_fwd_tile8(1 if on else 0)
 
-
-def set_backward_tile16(on: bool):
-    """Two-launch path: backward with 32x16 tiles of dW1 (default) or with 32x32 tiles."""
-    require().dtf_debug_set_bwd_tile16(1 if on else 0)

@@ -114,17 +114,15 @@ def _engine(device, B=100, K=784, H=100, C=10, act="sigmoid", with_grads=True, s
     return eng
 
 
-@pytest.fixture(params=["two_launch", "two_launch_coarse", "generic"])
+@pytest.fixture(params=["two_launch", "two_launch_fwd16", "generic"])
 def step_path(request):
-    """Every step implementation: the 2-launch small-batch path with the default fine tilings (8x8 forward
-    tiles, 32x16 backward tiles) and with the coarse ones (16x16 / 32x32), and the generic 3-launch path."""
+    """Every step implementation: the 2-launch small-batch path with the default 8x8 forward tiles and with the
+    generic 16x16-tile forward kernel (the fallback for K not a multiple of 4), and the generic 3-launch path."""
     hb.force_generic_path(request.param == "generic")
-    hb.set_forward_tile8(request.param != "two_launch_coarse")
-    hb.set_backward_tile16(request.param != "two_launch_coarse")
+    hb.set_forward_tile8(request.param != "two_launch_fwd16")
     yield request.param
     hb.force_generic_path(False)
     hb.set_forward_tile8(True)
-    hb.set_backward_tile16(True)
 
 
 @pytest.mark.parametrize("B,K,H,C,act", [(100, 784, 100, 10, "sigmoid"), (100, 784, 100, 10, "relu"),
