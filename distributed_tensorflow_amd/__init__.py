@@ -15,6 +15,7 @@ from .graph import *  # noqa: F401,F403
 from .graph import (Graph, GraphKeys, Tensor, Variable, get_default_graph, nn,  # noqa: F401
                     reset_default_graph)
 from .session import InteractiveSession, Session, get_default_session  # noqa: F401
+from .utils.trace import RunMetadata, RunOptions  # noqa: F401
 
 
 class _App:

@@ -102,6 +102,37 @@ def build_runtime(force: bool = False) -> Path:
     return RT_LIB
 
 
+SANITIZERS = {
+    "thread": ["-fsanitize=thread"],
+    "address": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+}
+STRESS_SOURCES = {
+    "server_stress": ["stress/server_stress.cpp", "ps_server.cpp"],
+    "records_stress": ["stress/records_stress.cpp", "records.cpp"],
+}
+
+
+def _sanitizer_cxx() -> str:
+    """clang++ of the ROCm toolchain: its sanitizer runtimes intercept the clock-based condition
+    variable waits libstdc++ uses; g++ 11's ThreadSanitizer does not and reports locks it never saw
+    released."""
+    for cand in (os.environ.get("DTF_SANITIZER_CXX"), "/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("no clang++ found for the sanitizer builds (set DTF_SANITIZER_CXX)")
+
+
+def build_stress(name: str, sanitizer: str, out_dir: Path) -> Path:
+    """Host-only sanitizer build of one stress program of the native runtime (``runtime/stress``)."""
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    exe = out_dir / f"{name}_{sanitizer}"
+    srcs = [str(RTSRC / rel) for rel in STRESS_SOURCES[name]]
+    _run([_sanitizer_cxx(), "-std=c++17", "-O1", "-g", "-pthread", *SANITIZERS[sanitizer], f"-I{RTSRC}", *srcs,
+          "-o", str(exe)])
+    return exe
+
+
 def build_all(force: bool = False):
     return [lib for lib in (build_hip(force), build_runtime(force)) if lib is not None]
 

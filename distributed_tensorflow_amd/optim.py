@@ -34,6 +34,7 @@ import time
 from typing import List, Optional, Sequence, Tuple
 
 from . import graph as G
+from .utils.trace import span
 
 
 class Optimizer:
@@ -112,13 +113,15 @@ class QueueRunner:
                         break
                     required = max(1, min(opt.replicas_to_aggregate, live))
                 try:
-                    step = store.take_apply_all(clients, required, opt.lr_value(), timeout=0.5)
+                    with span("aggregate_apply", required=required):
+                        step = store.take_apply_all(clients, required, opt.lr_value(), timeout=0.5)
                 except TimeoutError:
                     # nothing to aggregate yet; a replica that finished early no longer counts
                     live = store.live_workers(clients)
                     required = max(1, min(opt.replicas_to_aggregate, live if live > 0 else 1))
                     continue
-                store.enqueue_tokens(clients, step, opt.tokens_per_step)
+                with span("release_tokens", step=step):
+                    store.enqueue_tokens(clients, step, opt.tokens_per_step)
                 self.rounds += 1
                 idle_since = None
         except BaseException as e:  # surfaced by Supervisor.stop()

@@ -24,6 +24,7 @@ from __future__ import annotations
 import torch
 
 from ..models.mlp import MLPEngine
+from ..utils.trace import span
 from .replicas import _BaseTrainer
 
 
@@ -68,9 +69,12 @@ class PsResidentTrainer(_BaseTrainer):
             self.engine.reset_step_workspace(0)
 
     def _one_step(self, batch_index: int):
-        self.store.pull(self.params)
-        self.engine.step_grad(batch_index, 1.0)
-        self.store.push_apply(self.grads, self.lr_value, self.use_locking, bump_step=self.bump_step)
+        with span("pull"):
+            self.store.pull(self.params)
+        with span("step"):
+            self.engine.step_grad(batch_index, 1.0)
+        with span("push_apply"):
+            self.store.push_apply(self.grads, self.lr_value, self.use_locking, bump_step=self.bump_step)
 
     def _capture(self, pos: int, n: int, parity: int):
         # No warm-up replay here: a step writes the shared shards, which cannot be rolled back.

@@ -32,6 +32,7 @@ from typing import Optional, Tuple
 import torch
 
 from ..models.mlp import MLPEngine
+from ..utils.trace import span
 from ..ops import hip_backend as hb
 from ..ops import reference as ref
 from ..variables import ShardLayout, assign_shards, mlp_var_specs
@@ -136,7 +137,8 @@ class _BaseTrainer:
         g = self._graphs.get(key)
         if g is None:
             self._bind_set(dset)
-            g = self._capture(pos, n, parity)
+            with span("graph_capture", steps=n):
+                g = self._capture(pos, n, parity)
             self._graphs[key] = g
         return g
 
@@ -178,14 +180,17 @@ class _BaseTrainer:
         for k in self._schedule(self.engine._host_cursor, n):
             cur = self.engine._host_cursor
             if cur % bpe == 0 and cur > 0:
-                self.ds.shuffle_epoch()
+                with span("shuffle_epoch"):
+                    self.ds.shuffle_epoch()
             self._bind_set(getattr(self.ds, "active", 0))
             if self.use_graph:
-                self._get_graph(cur % bpe, k, self.engine.parity).replay()
+                with span("chunk_replay", steps=k):
+                    self._get_graph(cur % bpe, k, self.engine.parity).replay()
                 self.engine.parity ^= k & 1
                 self.engine._host_cursor += k
             else:
-                self._run_eager(cur % bpe, k)
+                with span("chunk_eager", steps=k):
+                    self._run_eager(cur % bpe, k)
             self.steps_done += k
 
     def evaluate(self, x, y):

@@ -42,6 +42,7 @@ void* dtf_server_start(const char* host, int port, int* out_port);
 int dtf_server_port(void* server);
 int dtf_server_wait(void* server, int timeout_ms);
 void dtf_server_stats(void* server, uint64_t* out3);
+int dtf_server_connections(void* server);
 void dtf_server_stop(void* server);
 
 void* dtf_client_connect(const char* host, int port, int timeout_ms);

@@ -32,6 +32,7 @@ import torch
 
 from . import graph as G
 from .cluster import ConfigProto, lookup_server
+from .utils.trace import Collector, span
 from .models.mlp import MLPEngine
 from .ops import hip_backend as hb
 from .optim import Optimizer, SyncReplicasOptimizer
@@ -223,7 +224,8 @@ class Session:
         return self.layout.view(self.theta, v.op_name)
 
     def _pull(self):
-        self.store.pull(self.theta)
+        with span("pull"):
+            self.store.pull(self.theta)
 
     def _run_init(self, variables: Sequence[G.Variable]):
         self._gs_mirror = None
@@ -235,6 +237,15 @@ class Session:
 
     # -- evaluation -------------------------------------------------------------------
     def run(self, fetches, feed_dict: Optional[Dict[G.Tensor, Any]] = None, options=None, run_metadata=None):
+        """``options=RunOptions(trace_level=...)`` records this call's phases into ``run_metadata.step_stats``."""
+        if options is not None and getattr(options, "wants_trace", False):
+            col = run_metadata.step_stats.collector if run_metadata is not None else Collector()
+            col.sync = bool(options.wants_device_time)
+            with col, span("session.run"):
+                return self._run(fetches, feed_dict)
+        return self._run(fetches, feed_dict)
+
+    def _run(self, fetches, feed_dict):
         if self._closed:
             raise RuntimeError("session is closed")
         single = not isinstance(fetches, (list, tuple))
@@ -492,9 +503,12 @@ class Session:
             xv = feed[m["x"]]
             batch = int(xv.shape[0])
             eng = self._engine_for(m, batch)
-            self._stage(eng, m, feed)
-            eng.step_grad(0, 1.0)
-            host = eng._stats.cpu()          # the step's only wait for the device
+            with span("stage"):
+                self._stage(eng, m, feed)
+            with span("step"):
+                eng.step_grad(0, 1.0)
+            with span("fetch_stats"):
+                host = eng._stats.cpu()          # the step's only wait for the device
             cache[m["loss"]] = host[0]
             cache[("acc", id(m["loss"]))] = host[1]
             for n in plan["acc_nodes"]:
@@ -505,8 +519,9 @@ class Session:
             var_list = train_op.attrs["var_list"]
             leaves = {v: self._var_view(v).detach().clone().requires_grad_(True) for v in var_list}
             fcache: Dict[G.Tensor, Any] = {}
-            loss_val = self._eval(train_op.attrs["loss"], feed, fcache, leaves)
-            grads = torch.autograd.grad(loss_val, [leaves[v] for v in var_list], allow_unused=True)
+            with span("step_generic"):
+                loss_val = self._eval(train_op.attrs["loss"], feed, fcache, leaves)
+                grads = torch.autograd.grad(loss_val, [leaves[v] for v in var_list], allow_unused=True)
             for v, g in zip(var_list, grads):
                 if g is not None:
                     self.layout.view(self.grad, v.op_name).copy_(g)
@@ -518,13 +533,18 @@ class Session:
             if not self._local_step_ready:
                 self.store.sync_local_step()
                 self._local_step_ready = True
-            self.store.push_accumulate(self.grad)
-            self.store.dequeue_token()
+            with span("push_accumulate"):
+                self.store.push_accumulate(self.grad)
+            with span("token_wait"):
+                self.store.dequeue_token()
         elif isinstance(opt, SyncReplicasOptimizer):
             # one local replica: aggregate of one
-            self.store.push_apply(self.grad, lr, True, bump_step=train_op.attrs["global_step"] is not None)
+            with span("push_apply"):
+                self.store.push_apply(self.grad, lr, True, bump_step=train_op.attrs["global_step"] is not None)
         else:
-            self.store.push_apply(self.grad, lr, opt.use_locking, bump_step=train_op.attrs["global_step"] is not None)
+            with span("push_apply"):
+                self.store.push_apply(self.grad, lr, opt.use_locking,
+                                      bump_step=train_op.attrs["global_step"] is not None)
 
     def _init_tokens(self, node):
         opt = node.attrs["optimizer"]

@@ -25,6 +25,7 @@ import torch
 
 from ..runtime import native as rt
 from ..summary import _parse_fields, _read_varint, _varint
+from ..utils.trace import mark, span
 
 CHECKPOINT_STATE = "checkpoint"
 
@@ -135,6 +136,10 @@ class Saver:
 
     def save(self, sess, save_path: str, global_step=None, latest_filename: str = CHECKPOINT_STATE,
              write_meta_graph: bool = True) -> str:
+        with span("checkpoint_save"):
+            return self._save(sess, save_path, global_step, latest_filename, write_meta_graph)
+
+    def _save(self, sess, save_path, global_step, latest_filename, write_meta_graph) -> str:
         if sess.store.is_remote:
             sess._pull()
         if global_step is not None:
@@ -178,6 +183,7 @@ class Saver:
         os.replace(prefix + ".meta.tmp", prefix + ".meta")
 
     def restore(self, sess, save_path: str):
+        mark("checkpoint_restore", path=save_path)
         values = read_bundle(save_path)
         for v in self._variables(sess):
             if v.op_name not in values:

@@ -1,0 +1,49 @@
+"""The native runtime under ThreadSanitizer and AddressSanitizer + UBSan (host code only).
+
+``runtime/stress/server_stress.cpp`` drives the task server with concurrent workers, a chief, connection
+churn and blocked readers; ``runtime/stress/records_stress.cpp`` writes event files and checkpoints from
+several threads and re-reads every record.  The lock-free variable paths (use_locking=False, the
+reference's default: tfdist_between.py:65) race on purpose and are excluded from ThreadSanitizer in
+the source; everything else must come out clean.
+"""
+import subprocess
+
+import pytest
+
+from distributed_tensorflow_amd import build
+
+pytestmark = pytest.mark.timeout(300)
+
+
+def _build(name, sanitizer, out_dir):
+    try:
+        return build.build_stress(name, sanitizer, out_dir)
+    except RuntimeError as e:
+        pytest.skip(f"sanitizer build unavailable: {e}")
+
+
+def _run(cmd):
+    r = subprocess.run(list(map(str, cmd)), capture_output=True, text=True, timeout=240)
+    text = r.stdout + r.stderr
+    assert r.returncode == 0, text[-4000:]
+    assert "OK" in r.stdout
+    for needle in ("ThreadSanitizer", "AddressSanitizer", "runtime error", "LeakSanitizer"):
+        assert needle not in text, text[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_task_server_is_clean_under_sanitizers(tmp_path, sanitizer):
+    exe = _build("server_stress", sanitizer, tmp_path)
+    out = _run([exe, 6, 80])
+    assert "workers=6 rounds=80" in out
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_record_writers_are_clean_under_sanitizers(tmp_path, sanitizer):
+    exe = _build("records_stress", sanitizer, tmp_path)
+    logdir = tmp_path / "logs"
+    logdir.mkdir()
+    _run([exe, logdir, 4, 200])
+    assert len(list(logdir.glob("events.out.tfevents.*"))) == 4
+    assert len(list(logdir.glob("model.ckpt-*.index"))) == 4
