@@ -5,6 +5,7 @@ on a process-wide registry; ``FLAGS.name`` parses ``sys.argv`` lazily on first
 attribute access (the reference never calls ``tf.app.run()``), accepting both
 ``--name=value`` and ``--name value``.  Unknown arguments are kept in
 ``FLAGS.unparsed`` instead of aborting, as with ``parse_known_args``.
+``--help`` / ``-h`` / ``--helpfull`` print the registered flags with their defaults and exit.
 """
 from __future__ import annotations
 
@@ -38,6 +39,9 @@ class _FlagValues:
         i = 0
         while i < len(args):
             a = args[i]
+            if a in ("--help", "-h", "-?", "--helpfull", "--helpshort"):
+                sys.stdout.write(self._usage())
+                sys.exit(0)
             if a.startswith("--"):
                 body = a[2:]
                 name, eq, val = body.partition("=")
@@ -62,6 +66,17 @@ class _FlagValues:
             i += 1
         object.__setattr__(self, "unparsed", rest)
         object.__setattr__(self, "_parsed", True)
+
+    def _usage(self) -> str:
+        prog = sys.argv[0] if sys.argv and sys.argv[0] else "program"
+        lines = [f"usage: {prog} [flags]", "", "flags:"]
+        for name in sorted(self._defs):
+            parser, default, help_ = self._defs[name]
+            kind = {str: "string", int: "integer", float: "float", _parse_bool: "boolean"}.get(parser, "value")
+            head = f"  --[no]{name}" if parser is _parse_bool else f"  --{name}=<{kind}>"
+            lines.append(f"{head}: {help_}".rstrip(": ") if not help_ else f"{head}: {help_}")
+            lines.append(f"    (default: {default!r})")
+        return "\n".join(lines) + "\n"
 
     def __getattr__(self, name: str):
         if name.startswith("_"):
@@ -111,6 +126,17 @@ def DEFINE_boolean(name: str, default: Optional[bool], help: str = ""):  # noqa:
 DEFINE_bool = DEFINE_boolean
 
 
+def DEFINE_enum(name: str, default: Optional[str], enum_values, help: str = ""):  # noqa: A002,N802
+    allowed = list(enum_values)
+
+    def parse(v: str) -> str:
+        if v not in allowed:
+            raise ValueError(f"flag --{name}={v!r}: value should be one of {allowed}")
+        return v
+
+    FLAGS._define(name, parse, default, (help + " " if help else "") + "<" + "|".join(allowed) + ">")
+
+
 class _FlagsModule:
     """Object exposed as ``app.flags`` (``tf.app.flags.DEFINE_string`` ... ``tf.app.flags.FLAGS``)."""
 
@@ -120,6 +146,7 @@ class _FlagsModule:
     DEFINE_float = staticmethod(DEFINE_float)
     DEFINE_boolean = staticmethod(DEFINE_boolean)
     DEFINE_bool = staticmethod(DEFINE_boolean)
+    DEFINE_enum = staticmethod(DEFINE_enum)
 
 
 flags = _FlagsModule()

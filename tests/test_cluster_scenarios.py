@@ -44,7 +44,9 @@ def test_readme_scenario(script, n_ps, n_w, tmp_path):
     if "sync" in script:
         assert finals == [11] * n_w                         # one update per N worker batches
     else:
-        assert max(finals) == 11 * n_w                      # every push is an update
+        # every push is an update; "Step" is the value pulled before a worker's own update, plus one
+        # (tfdist_between.py:102), so workers whose last batches overlap print the same number
+        assert 11 * n_w - (n_w - 1) <= max(finals) <= 11 * n_w
     if n_ps == 2:
         out = res["worker0"][1]                             # log_device_placement shows the round-robin shards
         assert "weights/Variable: (VariableV2): /job:ps/task:1" in out
@@ -63,7 +65,7 @@ def test_async_workers_on_the_device_resident_tier(tmp_path):
         assert "between-graph async worker, device-resident" in out
         steps, costs = _check_worker(out)
         finals.append(steps[-1])
-    assert max(finals) == 22                                # 2 workers x 11 pushes, every one an update
+    assert 21 <= max(finals) <= 22     # 2 workers x 11 pushes, every one an update (the last two may overlap)
     import os
     assert any(f.startswith("events.out.tfevents.") for f in os.listdir(tmp_path))   # per-step summaries kept
 

@@ -63,4 +63,9 @@ def test_reference_between_graph_scripts_run_unmodified(script, sync, tmp_path):
         steps = STEP_RE.findall(outs[f"w{i}"])
         assert steps and outs[f"w{i}"].rstrip().endswith("Done")
         finals.append(int(steps[-1][0]))
-    assert finals == [22, 22] if sync else max(finals) == 44
+    # 'Step' is the global step pulled BEFORE the worker's own update, plus one (tfdist_between.py:102): workers
+    # whose last batches overlap pull the same value, so up to n_w - 1 updates may be missing from the largest print
+    if sync:
+        assert finals == [22, 22]
+    else:
+        assert 43 <= max(finals) <= 44

@@ -36,6 +36,26 @@ def test_lazy_parse_from_argv(monkeypatch):
     assert fv.job_name == "ps"      # first attribute access parses sys.argv
 
 
+def test_help_lists_every_flag_and_exits(capsys):
+    fv = _fresh()
+    fv._define("job_name", str, "", "either 'ps' or 'worker'")
+    with pytest.raises(SystemExit) as e:
+        fv._parse(["--job_name=ps", "--help"])
+    assert e.value.code == 0
+    out = capsys.readouterr().out
+    assert "--job_name=<string>: either 'ps' or 'worker'" in out and "--[no]resident" in out
+    assert "--task_index=<integer>" in out and "(default: 0.001)" in out
+
+
+def test_enum_flag_rejects_other_values(monkeypatch):
+    monkeypatch.setattr(F, "FLAGS", F._FlagValues())
+    F.DEFINE_enum("transport", "tcp", ["tcp", "ipc"], "parameter-server transport")
+    F.FLAGS._parse(["--transport=ipc"])
+    assert F.FLAGS.transport == "ipc"
+    with pytest.raises(ValueError, match="one of"):
+        F.FLAGS._parse(["--transport", "carrier-pigeon"])
+
+
 def test_cluster_spec():
     c = ClusterSpec({"ps": ["a:1"], "worker": ["a:2", "b:3"]})
     assert c.num_tasks("worker") == 2 and c.task_address("worker", 1) == "b:3"

@@ -103,7 +103,12 @@ def test_ipc_transport_gpu_resident_shards(script, n_ps, n_w, tmp_path):
         assert out.rstrip().endswith("Done")
         steps = [int(s) for s in re.findall(r"Step: (\d+),", out)]
         finals.append(steps[-1])
-    assert finals == [11] * n_w if "sync" in script else max(finals) == 11 * n_w
+    # 'Step' is the global step pulled BEFORE the worker's own update, plus one (tfdist_between.py:102): workers
+    # whose last batches overlap pull the same value, so up to n_w - 1 updates may be missing from the largest print
+    if "sync" in script:
+        assert finals == [11] * n_w
+    else:
+        assert 11 * n_w - (n_w - 1) <= max(finals) <= 11 * n_w
 
 
 @pytest.mark.parametrize("n_ps,n_w", [(1, 1), (2, 2)])
@@ -126,7 +131,9 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
         assert out.rstrip().endswith("Done")
         finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
         costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
-    assert max(finals) == 2 * 22 * n_w
+    # 'Step' is the global step pulled BEFORE the worker's own update, plus one (tfdist_between.py:102): workers
+    # whose last batches overlap pull the same value, so up to n_w - 1 updates may be missing from the largest print
+    assert 2 * 22 * n_w - (n_w - 1) <= max(finals) <= 2 * 22 * n_w
     assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
 
 
