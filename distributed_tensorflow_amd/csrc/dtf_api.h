@@ -102,6 +102,22 @@ int dtf_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, flo
 int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int cols,
                     void* stream);
 
+// --- one-shot gradient all-reduce + SGD apply over peer-mapped HBM (xgmi.hip) -----------------
+#define DTF_XGMI_MAX_RANKS 16
+int dtf_xgmi_max_ranks(void);
+int dtf_xgmi_table_entries(void);
+// Zero-filled device memory that other processes may map; uncached != 0 for words that one GPU
+// polls while another writes them.
+int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached);
+int dtf_xgmi_free(void* p);
+int dtf_xgmi_export(void* p, void* handle64);
+int dtf_xgmi_open(const void* handle64, void** out);
+int dtf_xgmi_close(void* p);
+// params -= lr * sum over ranks of their gradient slab `slot`; global_step += 1.  See xgmi.hip.
+int dtf_xgmi_allreduce_apply(const uint64_t* table, int slot, const uint32_t* my_flags, float* params, int64_t n,
+                             const float* lr, float* global_step, uint32_t* state, int rank, int world,
+                             int timeout_ms, void* stream);
+
 const char* dtf_hip_build_info(void);
 
 #ifdef __cplusplus

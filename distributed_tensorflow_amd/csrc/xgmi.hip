@@ -1,0 +1,239 @@
+// One-shot gradient all-reduce fused with the SGD apply, over peer-mapped HBM.
+//
+// N replicas (one process per GPU, or several processes on one GPU) each hold
+//   * two gradient slabs (even / odd steps) that every peer maps through HIP-IPC,
+//   * a small array of arrival flags in uncached memory that the peers write into.
+// A step's exchange is ONE kernel per replica:
+//
+//   announce   block 0 publishes "my gradient of exchange s is complete" by storing s
+//              into its slot of every peer's flag array (release, system scope: the
+//              gradient written by the preceding backward kernel is flushed first);
+//   wait       every block polls the LOCAL flag array until all peers have announced s
+//              (bounded by a wall-clock limit: on expiry the kernel records an error,
+//              skips the update and still terminates);
+//   reduce     acquire at system scope, then each thread reads the same 16 bytes of all
+//              N slabs -- its own from local HBM, the others over xGMI, all loads in
+//              flight together -- and adds them in rank order, so every replica computes
+//              bit-identical sums;
+//   apply      p -= lr * sum on the local replica of the variables, global_step += 1.
+//
+// The mean of the reference's SyncReplicasOptimizer (tfdist_between_sync.py:65-68) comes
+// from gradients that the backward kernel already scaled by 1/N.  With 318 KB per
+// replica the exchange is latency-bound: one flag round trip plus one remote read, instead
+// of the several ring steps of a library all-reduce.  All peers reach every link of the
+// fully connected xGMI mesh at once (7 x 318 KB inbound per GPU per step).
+//
+// Why two slabs are enough: a replica overwrites slab (s+1)&1 only after it passed the wait
+// of exchange s, i.e. after every peer has STARTED exchange s, and a peer starts exchange s
+// only after its own exchange s-1 -- the last reader of slab (s-1)&1 -- has finished.
+#include <cstring>
+
+#include "dtf_api.h"
+#include "dtf_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxRanks = DTF_XGMI_MAX_RANKS;
+
+// Layout of the device-resident pointer table (uint64 entries).
+constexpr int kTabGrad0 = 0;                  // [rank] gradient slab of even exchanges
+constexpr int kTabGrad1 = kMaxRanks;          // [rank] gradient slab of odd exchanges
+constexpr int kTabFlags = 2 * kMaxRanks;      // [rank] base of that rank's arrival-flag array
+// state words
+constexpr int kSeq = 0, kDone = 1, kError = 2;
+
+struct XgmiArgs {
+  const uint64_t* table;
+  const uint32_t* my_flags;
+  float* params;
+  int64_t n;
+  const float* lr;
+  float* global_step;
+  uint32_t* state;
+  int slot, rank, world;
+  int64_t timeout_ticks;
+};
+
+template <int W>
+__device__ __forceinline__ void reduce_apply(const XgmiArgs& a, const float* const* grad, int world) {
+  const float lr = *a.lr;
+  const int64_t nvec = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  f32x4* p4 = reinterpret_cast<f32x4*>(a.params);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    f32x4 sum;
+    const f32x4 p = p4[i];
+    if (W > 0) {
+      f32x4 v[W > 0 ? W : 1];
+#pragma unroll
+      for (int r = 0; r < W; ++r) v[r] = reinterpret_cast<const f32x4*>(grad[r])[i];
+      sum = v[0];
+#pragma unroll
+      for (int r = 1; r < W; ++r) sum = sum + v[r];
+    } else {
+      sum = reinterpret_cast<const f32x4*>(grad[0])[i];
+      for (int r = 1; r < world; ++r) sum = sum + reinterpret_cast<const f32x4*>(grad[r])[i];
+    }
+    p4[i] = p - lr * sum;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (t < a.n) {
+      float sum = grad[0][t];
+      for (int r = 1; r < world; ++r) sum += grad[r][t];
+      a.params[t] -= lr * sum;
+    }
+    // thread 0 of block 0 also owns vector 0, so a global_step that lives inside the slab is
+    // updated after its (zero-gradient) SGD write, in program order
+    if (threadIdx.x == 0 && a.global_step) *a.global_step += 1.0f;
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void xgmi_allreduce_apply_kernel(XgmiArgs a) {
+  __shared__ int failed;
+  __shared__ const float* grad[kMaxRanks];
+  const int tid = threadIdx.x;
+  const int world = W > 0 ? W : a.world;
+  const uint32_t seq = __hip_atomic_load(&a.state[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t poisoned = __hip_atomic_load(&a.state[kError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) failed = poisoned ? 1 : 0;
+  if (tid < world) grad[tid] = reinterpret_cast<const float*>(a.table[(a.slot ? kTabGrad1 : kTabGrad0) + tid]);
+  __syncthreads();
+
+  if (!poisoned) {
+    if (blockIdx.x == 0 && tid < world && tid != a.rank) {
+      uint32_t* theirs = reinterpret_cast<uint32_t*>(a.table[kTabFlags + tid]);
+      __hip_atomic_store(&theirs[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tid < world && tid != a.rank) {
+      const long long t0 = wall_clock64();
+      while ((int32_t)(__hip_atomic_load(&a.my_flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (!failed) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: peers' slabs are read fresh
+      reduce_apply<W>(a, grad, world);
+    }
+  }
+
+  __syncthreads();
+  if (tid == 0) {
+    if (failed && !poisoned) atomicExch(&a.state[kError], 1u);
+    __threadfence();
+    const uint32_t done = atomicAdd(&a.state[kDone], 1u);
+    if (done == gridDim.x - 1) {      // last block out: the next launch on this stream sees seq + 1
+      __hip_atomic_store(&a.state[kDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.state[kSeq], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int dtf_xgmi_max_ranks(void) { return kMaxRanks; }
+
+extern "C" int dtf_xgmi_table_entries(void) { return 3 * kMaxRanks; }
+
+// Device memory that peers may map.  uncached != 0: fine-grained memory that no L2 keeps a copy
+// of, for words one GPU polls while another writes them.  The memory is zero-filled.
+extern "C" int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached) {
+  if (!out || bytes <= 0) return DTF_ERR_NULL;
+  void* p = nullptr;
+  hipError_t rc = uncached ? hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached)
+                           : hipMalloc(&p, (size_t)bytes);
+  if (rc != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return DTF_ERR_LAUNCH;
+  }
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return DTF_ERR_LAUNCH;
+  }
+  *out = p;
+  return DTF_OK;
+}
+
+extern "C" int dtf_xgmi_free(void* p) {
+  if (!p) return DTF_OK;
+  return hipFree(p) == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// handle: 64 bytes (hipIpcMemHandle_t), valid in other processes of this node.
+extern "C" int dtf_xgmi_export(void* p, void* handle) {
+  if (!p || !handle) return DTF_ERR_NULL;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return DTF_ERR_LAUNCH;
+  }
+  std::memcpy(handle, &h, sizeof(h));
+  return DTF_OK;
+}
+
+extern "C" int dtf_xgmi_open(const void* handle, void** out) {
+  if (!handle || !out) return DTF_ERR_NULL;
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return DTF_ERR_LAUNCH;
+  }
+  *out = p;
+  return DTF_OK;
+}
+
+extern "C" int dtf_xgmi_close(void* p) {
+  if (!p) return DTF_OK;
+  return hipIpcCloseMemHandle(p) == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// One exchange of replica `rank`: see the file header.  `table` is the device-resident pointer
+// table (dtf_xgmi_table_entries() uint64 words: even-step slabs, odd-step slabs, flag arrays, each
+// indexed by rank; the entries of `rank` itself are its local pointers), `slot` the parity of the
+// exchange the preceding backward wrote its gradient for, `state` three zero-initialised words in
+// local device memory whose first one must be set to 1 before the first exchange.
+extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* table, int slot, const uint32_t* my_flags, float* params,
+                                        int64_t n, const float* lr, float* global_step, uint32_t* state, int rank,
+                                        int world, int timeout_ms, void* stream) {
+  if (!table || !my_flags || !params || !lr || !state) return DTF_ERR_NULL;
+  if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world || n < 0 || (slot != 0 && slot != 1))
+    return DTF_ERR_SHAPE;
+  if (!aligned16(params)) return DTF_ERR_SHAPE;
+  XgmiArgs a;
+  a.table = table;
+  a.my_flags = my_flags;
+  a.params = params;
+  a.n = n;
+  a.lr = lr;
+  a.global_step = global_step;
+  a.state = state;
+  a.slot = slot;
+  a.rank = rank;
+  a.world = world;
+  a.timeout_ticks = (int64_t)(timeout_ms > 0 ? timeout_ms : 5000) * 100000;   // 100 MHz wall clock
+  int64_t blocks = ((n >> 2) + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;      // every block must be resident while it waits
+  const dim3 grid((unsigned)blocks), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  switch (world) {
+    case 2: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<2>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<4>, grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<8>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<0>, grid, block, 0, s, a); break;
+  }
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}

@@ -88,6 +88,8 @@ class MLPEngine:
         self._gram = None
         self._pipe = None
         self._pipe_bufs = None
+        self._grad_slots = None
+        self._slot_descs = {}
 
     # -- data ---------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -232,16 +234,45 @@ class MLPEngine:
         else:
             self._cpu_step(bi, True, 1.0)
 
-    def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0):
-        """Gradients of mini-batch ``batch_index`` into the gradient tensors; no update."""
-        if self.g is None:
+    def bind_grad_slots(self, slots):
+        """Alternative gradient outputs: ``slots[s]`` is a dict like ``grads``; ``step_grad(slot=s)`` writes
+        there.  Used by exchanges that double-buffer the gradient (peers read step t's while t+1 is computed)."""
+        for g in slots:
+            for k in self.PARAM_NAMES:
+                if g[k].shape != self.p[k].shape or not g[k].is_contiguous() or g[k].dtype != torch.float32:
+                    raise ValueError(f"gradient slot {k} must be contiguous float32 and parameter-shaped")
+        self._grad_slots = [{k: g[k] for k in self.PARAM_NAMES} for g in slots]
+        self._slot_descs = {}
+
+    def _slot_descriptor(self, slot: int) -> "hb.DtfMlpDesc":
+        base = self._descriptor()
+        cached = self._slot_descs.get(slot)
+        if cached is not None and cached[0] is base:
+            return cached[1]
+        d = hb.DtfMlpDesc.from_buffer_copy(base)
+        for k in self.PARAM_NAMES:
+            setattr(d, "g" + k, self._grad_slots[slot][k].data_ptr())
+        self._slot_descs[slot] = (base, d)
+        return d
+
+    def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0, slot: Optional[int] = None):
+        """Gradients of mini-batch ``batch_index`` into the gradient tensors (or into gradient slot ``slot``,
+        see :meth:`bind_grad_slots`); no update."""
+        if self.g is None and slot is None:
             raise RuntimeError("engine was built without gradient tensors")
         bi = self._bi(batch_index)
         if self.on_gpu:
-            hb.mlp_step_grad(self._descriptor(), bi, self.parity, scale)
+            d = self._descriptor() if slot is None else self._slot_descriptor(slot)
+            hb.mlp_step_grad(d, bi, self.parity, scale)
             self.parity ^= 1
-        else:
+        elif slot is None:
             self._cpu_step(bi, False, scale)
+        else:
+            keep, self.g = self.g, self._grad_slots[slot]
+            try:
+                self._cpu_step(bi, False, scale)
+            finally:
+                self.g = keep
 
     def advance(self, n: int = 1):
         self._host_cursor += n

@@ -328,9 +328,78 @@ class AsyncAllToAllTrainer(_CollectiveTrainer):
                 f"owning shard, all-gather pull" + (", hipGraph" if self.use_graph else ", eager"))
 
 
+class XgmiTowerTrainer(_BaseTrainer):
+    """Synchronous replicas whose gradient exchange is ONE kernel over peer-mapped HBM.
+
+    Same update as ``TowerTrainer`` (the mean of N gradients applied once to every replica), but the
+    all-reduce and the SGD apply are a single launch that reads the peers' gradient slabs directly over
+    xGMI (``csrc/xgmi.hip``, ``parallel/xgmi.py``): 3 launches per step and no library collective.
+    The sum is taken in rank order on every replica, so the replicas stay bit-identical;
+    ``replica_checksum()`` lets a caller verify exactly that.
+    """
+
+    name = "xgmi"
+
+    def __init__(self, *a, group=None, local_peers: bool = False, uncached_grads: bool = False,
+                 timeout_ms: int = 20000, **kw):
+        kw["need_grads"] = False
+        super().__init__(*a, **kw)
+        if self.device.type != "cuda":
+            raise RuntimeError("the peer-mapped exchange is a GPU path")
+        from .xgmi import XgmiExchange
+
+        if self.layout.var_range["global_step"][0] >= 4:
+            raise RuntimeError("global_step must live in the first 16 bytes of the slab")
+        self.xg = XgmiExchange(self.rank, self.world, self.params.numel(), self.device, group=group,
+                               uncached_grads=uncached_grads, timeout_ms=timeout_ms, connect=not local_peers)
+        self.engine.bind_grad_slots([self.layout.mlp_views(g) for g in self.xg.grads])
+        self.group = group
+
+    def _one_step(self, batch_index: int):
+        # The slot follows the engine's step parity: consecutive steps alternate between the two slabs,
+        # which is what lets a peer still read step t's gradient while step t+1 is being computed.
+        slot = self.engine.parity
+        self.engine.step_grad(batch_index, scale=1.0 / self.world, slot=slot)
+        self.xg.apply(self.params, self.lr, slot, self.global_step)
+
+    def _capture(self, pos: int, n: int, parity: int):
+        # Warm-up exchanges are real exchanges (every replica performs the same number of them) whose
+        # results are rolled back; two of them, so that the slots keep alternating.
+        snap = self._snapshot()
+        self.engine.reset_step_workspace(parity)
+        for i in range(2):
+            self._one_step(pos)
+        torch.cuda.synchronize(self.device)
+        self._restore(snap)
+        self.engine.reset_step_workspace(parity)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for i in range(n):
+                self._one_step(pos + i)
+        self.engine.parity = parity
+        return graph
+
+    def replica_checksum(self) -> int:
+        """Bitwise checksum of the local replica of the variables (equal on all replicas when in sync)."""
+        return int(self.params.view(torch.int32).to(torch.int64).sum().item())
+
+    def healthy(self) -> bool:
+        return not self.xg.failed()
+
+    def close(self):
+        self._graphs.clear()
+        self.xg.close()
+
+    def describe(self):
+        return (f"sync towers dp{self.world}: one-kernel gradient exchange over peer-mapped HBM "
+                f"(announce, wait, sum of {self.world} slabs in rank order, SGD apply), 3 launches/step"
+                + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
+
+
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async": AsyncAllToAllTrainer}[mode]
+           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer}[mode]
     if mode == "single" and kw.get("world", 1) != 1:
         raise ValueError("single mode is one process")
     return cls(**kw)

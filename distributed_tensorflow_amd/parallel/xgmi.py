@@ -1,0 +1,179 @@
+"""Peer-mapped gradient exchange: the buffers and handles behind ``csrc/xgmi.hip``.
+
+Every replica (one process per GPU, or several processes on one GPU in tests) owns
+
+* two gradient slabs — the backward kernel of step *t* writes slab ``t & 1`` —
+* an array of arrival flags in uncached memory, one word per peer,
+* three words of local state (exchange number, finished blocks, error),
+
+exports the first two as HIP-IPC handles, maps those of every peer, and stores all the
+pointers in a small device table.  ``apply()`` then launches ONE kernel that announces the
+local gradient, waits for the peers' announcements, sums the N slabs in rank order straight out
+of the peers' HBM and applies ``p -= lr * sum`` to the local replica of the variables.
+
+This is the synchronous data-parallel update of the reference (the mean gradient applied once
+per N worker batches, tfdist_between_sync.py:65-68) with the all-reduce and the optimizer fused
+into one launch; it replaces a library all-reduce whose ring steps dominate a 318 KB message.
+
+The handles travel through any ``torch.distributed`` group (``all_gather_object``); the group is
+used for set-up only, never per step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from ..ops import hip_backend as hb
+
+HANDLE_BYTES = 64
+
+
+class _DeviceBuffer:
+    """Memory from ``dtf_xgmi_alloc`` exposed to torch through ``__cuda_array_interface__``."""
+
+    def __init__(self, ptr: int, nbytes: int, typestr: str, itemsize: int, owner: bool):
+        self.ptr, self.nbytes, self.owner = ptr, nbytes, owner
+        self.__cuda_array_interface__ = {"shape": (nbytes // itemsize,), "typestr": typestr,
+                                         "data": (ptr, False), "version": 2, "strides": None}
+
+
+def _alloc(nbytes: int, uncached: bool) -> int:
+    out = C.c_void_p()
+    hb._check(hb.require().dtf_xgmi_alloc(C.byref(out), int(nbytes), int(uncached)), "dtf_xgmi_alloc")
+    return int(out.value)
+
+
+def _export(ptr: int) -> bytes:
+    buf = C.create_string_buffer(HANDLE_BYTES)
+    hb._check(hb.require().dtf_xgmi_export(ptr, buf), "dtf_xgmi_export")
+    return buf.raw
+
+
+def _open(handle: bytes) -> int:
+    out = C.c_void_p()
+    hb._check(hb.require().dtf_xgmi_open(C.create_string_buffer(handle, HANDLE_BYTES), C.byref(out)), "dtf_xgmi_open")
+    return int(out.value)
+
+
+class XgmiExchange:
+    """Buffers, peer mappings and the pointer table of one replica.
+
+    ``numel``: floats per gradient slab (padded to a multiple of 4 internally).  ``group``: the
+    ``torch.distributed`` group used to swap handles (None with ``world == 1`` or when the peers
+    are handed in through ``connect_local``).  ``uncached_grads``: keep the gradient slabs out of
+    every L2 as well (slower stores in the backward kernel; the flags always are).
+    """
+
+    def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None,
+                 uncached_grads: bool = False, timeout_ms: int = 5000, connect: bool = True):
+        lib = hb.require()
+        if not 1 <= world <= lib.dtf_xgmi_max_ranks():
+            raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.numel = int(numel)
+        self.padded = (self.numel + 3) // 4 * 4
+        self.timeout_ms = int(timeout_ms)
+        self._max = lib.dtf_xgmi_max_ranks()
+        self._closed = False
+        self._mapped: List[int] = []
+        with torch.cuda.device(self.device):
+            slab_bytes = 2 * self.padded * 4
+            self._grad_ptr = _alloc(slab_bytes, uncached_grads)
+            self._flag_ptr = _alloc(4096, True)
+            self._grad_buf = _DeviceBuffer(self._grad_ptr, slab_bytes, "<f4", 4, True)
+            both = torch.as_tensor(self._grad_buf, device=self.device)
+            self.grads = [both[: self.padded][: self.numel], both[self.padded:][: self.numel]]
+            self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.state[0] = 1                                   # exchanges are numbered from 1; flags start at 0
+            self.table = torch.zeros(lib.dtf_xgmi_table_entries(), dtype=torch.int64, device=self.device)
+        self._peer_grad = [0] * self.world
+        self._peer_flag = [0] * self.world
+        self._peer_grad[self.rank], self._peer_flag[self.rank] = self._grad_ptr, self._flag_ptr
+        if connect:
+            self.connect(group)
+
+    # -- wiring -----------------------------------------------------------------------
+    def handles(self) -> dict:
+        return {"rank": self.rank, "grad": _export(self._grad_ptr), "flag": _export(self._flag_ptr),
+                "padded": self.padded}
+
+    def connect(self, group=None):
+        """Swap IPC handles over ``group`` and map every peer's buffers."""
+        if self.world > 1:
+            import torch.distributed as dist
+
+            mine = self.handles()
+            everyone: List[Optional[dict]] = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=group)
+            with torch.cuda.device(self.device):
+                for h in everyone:
+                    r = h["rank"]
+                    if r == self.rank:
+                        continue
+                    if h["padded"] != self.padded:
+                        raise RuntimeError("replicas disagree on the slab size")
+                    self._peer_grad[r] = _open(h["grad"])
+                    self._peer_flag[r] = _open(h["flag"])
+                    self._mapped += [self._peer_grad[r], self._peer_flag[r]]
+        self._write_table()
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier(group=group)     # nobody announces into a flag array that is not mapped yet
+
+    def connect_local(self, peers: List["XgmiExchange"]):
+        """Replicas that live in ONE process (tests, in-graph towers on one GPU): plain pointers."""
+        for p in peers:
+            self._peer_grad[p.rank], self._peer_flag[p.rank] = p._grad_ptr, p._flag_ptr
+        self._write_table()
+
+    def _write_table(self):
+        m = self._max
+        host = [0] * (3 * m)
+        for r in range(self.world):
+            host[r] = self._peer_grad[r]
+            host[m + r] = self._peer_grad[r] + self.padded * 4
+            host[2 * m + r] = self._peer_flag[r]
+        self.table.copy_(torch.tensor(host, dtype=torch.int64))
+        torch.cuda.synchronize(self.device)
+
+    # -- per step ----------------------------------------------------------------------
+    def apply(self, params: torch.Tensor, lr: torch.Tensor, slot: int, global_step: Optional[torch.Tensor] = None):
+        """``params -= lr * sum_r grads_r[slot]`` (+ ``global_step += 1``) on the current stream."""
+        if params.numel() != self.numel:
+            raise ValueError("parameter slab and gradient slabs differ in size")
+        hb._check(hb.require().dtf_xgmi_allreduce_apply(
+            self.table.data_ptr(), int(slot) & 1, self._flag_ptr, params.data_ptr(), self.numel, lr.data_ptr(),
+            None if global_step is None else global_step.data_ptr(), self.state.data_ptr(), self.rank, self.world,
+            self.timeout_ms, torch.cuda.current_stream(self.device).cuda_stream), "dtf_xgmi_allreduce_apply")
+
+    def failed(self) -> bool:
+        """True once an exchange gave up waiting for a peer (reads the device word: synchronises)."""
+        return bool(int(self.state[2].item()))
+
+    def exchanges_done(self) -> int:
+        return int(self.state[0].item()) - 1
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        lib = hb.require()
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:  # noqa: BLE001 — tearing down after a device error
+            pass
+        with torch.cuda.device(self.device):
+            for p in self._mapped:
+                lib.dtf_xgmi_close(p)
+            self.grads = []
+            lib.dtf_xgmi_free(self._grad_ptr)
+            lib.dtf_xgmi_free(self._flag_ptr)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

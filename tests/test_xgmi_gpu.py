@@ -1,0 +1,57 @@
+"""The one-kernel gradient exchange over peer-mapped HBM, several replica processes sharing the GPU.
+
+On one device the peers' slabs are reached through HIP-IPC mappings of the same HBM, which exercises
+the handle exchange, the pointer table, the announce / wait protocol, the slot alternation and the
+rank-ordered sum; the xGMI hop itself needs a multi-GPU node.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_replicas(world, steps, use_graph, uncached=0, timeout=150):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_xgmi_worker.py"), str(r), str(world), str(port),
+                               str(steps), str(int(use_graph)), str(int(uncached))],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    results = []
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+        results.append(json.loads([line for line in out.splitlines() if line.startswith("{")][-1]))
+    return results
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,use_graph,uncached", [(2, False, 0), (2, True, 0), (4, True, 0), (3, True, 1)])
+def test_replicas_stay_bit_identical_and_track_the_mean_gradient_reference(world, use_graph, uncached):
+    steps = 7
+    for r in _run_replicas(world, steps, use_graph, uncached):
+        assert r["healthy"], r
+        assert r["identical"] and r["same_sum"], r
+        assert r["global_step"] == steps
+        assert r["moved"] > 1e-3                                   # the run did train
+        assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r      # fp32 reference, different summation order
+        assert "peer-mapped" in r["describe"]
