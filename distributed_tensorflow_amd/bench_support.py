@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import os
+import sys
 import time
 from typing import Optional
 
@@ -30,6 +31,50 @@ def _sync(device, distributed: bool):
         torch.cuda.synchronize(device)
 
 
+def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int) -> dict:
+    """Run the peer-mapped exchange once in a child process per rank (see parallel/xgmi_probe.py).
+
+    Called before this process initialises the GPU.  Whatever happens to the child - a refused
+    mapping, a timeout in the exchange, replicas that disagree, a crash - stays in the child."""
+    import json
+    import subprocess
+
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 37
+    cmd = [sys.executable, "-m", "distributed_tensorflow_amd.parallel.xgmi_probe", "--rank", str(rank),
+           "--world", str(world), "--device", str(local_rank), "--port", str(port), "--chunk", str(chunk)]
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+    # The child makes a rendezvous of its own: nothing of the launcher's may leak into it (with
+    # TORCHELASTIC_USE_AGENT_STORE set, rank 0 would not host the store it is asked to connect to).
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                  "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+                                                  "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+            env.pop(k)
+    def attempt(extra, port_shift):
+        cmd[cmd.index("--port") + 1] = str(port + port_shift)
+        try:
+            r = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=150)
+        except subprocess.TimeoutExpired:
+            return {"ok": False, "error": "trial timed out"}
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                try:
+                    return json.loads(line)
+                except ValueError:
+                    break
+        return {"ok": False, "error": f"trial exited {r.returncode}: {r.stdout[-300:]}"}
+
+    res = attempt([], 0)
+    res["uncached_grads"] = False
+    # Replicas that ran to the end but disagree read a peer's gradient stale: every rank sees the same verdict
+    # (it is computed from all ranks' checksums), so every rank repeats the trial with the slabs uncached too.
+    if not res.get("ok") and res.get("identical") is False and res.get("healthy"):
+        res = attempt(["--uncached", "1"], 1)
+        res["uncached_grads"] = True
+    return res
+
+
 def run_benchmark(args) -> Optional[dict]:
     import torch.distributed as dist
 
@@ -43,16 +88,32 @@ def run_benchmark(args) -> Optional[dict]:
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
     if n > 1 and not distributed:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    use_cpu = bool(args.cpu) or not torch.cuda.is_available()
+    mode = args.mode or ("single" if n == 1 else "auto")
+    # device_count() does not create a GPU context, so the trial below still runs ahead of ours
+    use_cpu = bool(args.cpu) or torch.cuda.device_count() == 0
+    # Test hook: every rank on GPU 0 with a gloo rendezvous (RCCL refuses two ranks on one device), so that
+    # the whole multi-rank flow can be rehearsed on a one-GPU machine.
+    share_gpu = os.environ.get("DTF_BENCH_SHARE_GPU") == "1" and not use_cpu
+    dev_index = 0 if share_gpu else local_rank
+    trial = None
+    if mode == "auto" and distributed and not use_cpu and os.environ.get("DTF_BENCH_XGMI", "1") != "0":
+        trial = _trial_xgmi(rank, dev_index, world, int(args.chunk))
+    use_cpu = use_cpu or not torch.cuda.is_available()
     if use_cpu:
         device = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
     if distributed:
-        dist.init_process_group(backend="gloo" if use_cpu else "nccl",
-                                device_id=None if use_cpu else device)
-    mode = args.mode or ("single" if n == 1 else "auto")
+        lib_backend = not (use_cpu or share_gpu)
+        dist.init_process_group(backend="nccl" if lib_backend else "gloo", device_id=device if lib_backend else None)
+    xgmi_ok = False
+    if trial is not None:
+        flag = torch.tensor([1 if trial.get("ok") else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        xgmi_ok = bool(int(flag.item()))
+        if rank == 0 and not xgmi_ok:
+            print(f"[bench] peer-mapped exchange not used on this node: {trial}", flush=True)
 
     sizes = (55000, 5000, 10000) if not use_cpu else (5500, 100, 1000)
     mnist = read_data_sets("MNIST_data", one_hot=True, seed=0, sizes=sizes)
@@ -61,9 +122,11 @@ def run_benchmark(args) -> Optional[dict]:
     steps, warmup = int(args.steps), int(args.warmup)
 
     def build(m):
+        # gloo collectives (the one-GPU rehearsal) cannot be captured; the peer-mapped exchange can
+        graph = not args.no_graph and not (share_gpu and m != "xgmi")
+        extra = {"uncached_grads": bool(trial and trial.get("uncached_grads"))} if m == "xgmi" else {}
         return build_replica_trainer(mode=m, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
-                                     rank=rank, world=world, chunk=int(args.chunk),
-                                     use_graph=not args.no_graph)
+                                     rank=rank, world=world, chunk=int(args.chunk), use_graph=graph, **extra)
 
     def prepare(trainer, hint):
         # Capture the hipGraph chunks outside the timed region.  If capture fails on any rank
@@ -74,7 +137,10 @@ def run_benchmark(args) -> Optional[dict]:
         except Exception as e:  # noqa: BLE001
             ok = 0
             print(f"[bench rank {rank}] graph capture failed ({type(e).__name__}: {e}); using eager launches",
-                  flush=True)
+                  file=sys.stderr, flush=True)
+            if device.type == "cuda":
+                # a capture that died may leave its side stream current: go back to the default stream
+                torch.cuda.set_stream(torch.cuda.default_stream(device))
         if distributed:
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -84,15 +150,27 @@ def run_benchmark(args) -> Optional[dict]:
             trainer._graphs.clear()
             trainer.engine.reset_step_workspace(trainer.engine.parity)
 
-    # Two synchronous data-parallel exchanges compute the same update (the mean gradient applied once):
+    def retire(tr):
+        tr._graphs.clear()
+        if hasattr(tr, "close"):
+            _sync(device, distributed)
+            tr.close()
+
+    # Three synchronous data-parallel exchanges compute the same update (the mean gradient applied once):
     # PS shard per GPU (reduce-scatter -> sharded SGD -> all-gather) and replicated apply after one
-    # all-reduce.  Which one is faster for a 318 KB message is a property of the RCCL build and the
-    # xGMI topology, so "auto" times a short probe of each (untimed, before the warm-up) and keeps the winner.
+    # all-reduce, both over RCCL, and the one-kernel exchange over peer-mapped HBM (parallel/xgmi.py; offered
+    # only after its trial run in a child process succeeded on this node).  Which one is faster for a 318 KB
+    # message is a property of the RCCL build and the xGMI topology, so "auto" times a short probe of each
+    # (untimed, before the warm-up) and keeps the winner.
     probe_ms = None
     if mode == "auto":
         probe = max(2 * int(args.chunk), 100)
         probe_ms, best = {}, None
-        for cand in ("sync", "towers"):
+        # (the one-GPU rehearsal keeps its gloo group out of the per-step path whenever it can)
+        library = ("sync", "towers") if not share_gpu else (() if xgmi_ok else ("towers",))
+        for cand in library + (("xgmi",) if xgmi_ok else ()):
+            if rank == 0:
+                print(f"[bench] probing {cand}", file=sys.stderr, flush=True)
             t = build(cand)
             prepare(t, (probe, probe))
             t.run_steps(probe)
@@ -107,18 +185,44 @@ def run_benchmark(args) -> Optional[dict]:
             if best is None or probe_ms[cand] < probe_ms[best[0]]:
                 best = (cand, t)
             else:
-                t._graphs.clear()
+                retire(t)
                 del t
         mode, trainer = best
+        if mode != "xgmi":
+            fallback_mode = None
+        else:
+            fallback_mode = min((m for m in probe_ms if m != "xgmi"), key=lambda m: probe_ms[m], default=None)
     else:
         trainer = build(mode)
-    prepare(trainer, (warmup, steps, STEPS_PER_EPOCH))
-    trainer.run_steps(warmup)
-    _sync(device, distributed)
-    t0 = time.perf_counter()
-    trainer.run_steps(steps)
-    _sync(device, distributed)
-    elapsed = time.perf_counter() - t0
+        fallback_mode = None
+
+    def timed(tr):
+        prepare(tr, (warmup, steps, STEPS_PER_EPOCH))
+        tr.run_steps(warmup)
+        _sync(device, distributed)
+        t0 = time.perf_counter()
+        tr.run_steps(steps)
+        _sync(device, distributed)
+        return time.perf_counter() - t0
+
+    elapsed = timed(trainer)
+    if mode == "xgmi":
+        # The replicas sum in rank order, so they must be bit-identical; anything else (or an exchange that
+        # timed out) voids the measurement and the run is repeated with the library collectives.
+        good = torch.tensor([1 if trainer.healthy() else 0, trainer.replica_checksum()], dtype=torch.int64,
+                            device=device)
+        seen = [torch.zeros_like(good) for _ in range(world)] if distributed else [good]
+        if distributed:
+            dist.all_gather(seen, good)
+        consistent = all(int(g[0]) == 1 and int(g[1]) == int(seen[0][1]) for g in seen)
+        if not consistent and fallback_mode is not None:
+            if rank == 0:
+                print("[bench] replicas disagree after the peer-mapped run; repeating with " + fallback_mode, flush=True)
+            retire(trainer)
+            mode, trainer = fallback_mode, build(fallback_mode)
+            elapsed = timed(trainer)
+        elif not consistent:
+            raise SystemExit("peer-mapped exchange: replicas disagree")
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -181,6 +285,12 @@ def run_benchmark(args) -> Optional[dict]:
         }
         if probe_ms is not None:
             result["mode_probe_ms_per_step"] = probe_ms
+        if trial is not None:
+            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "error")
+                                             if k in trial}
+    if hasattr(trainer, "close"):
+        _sync(device, distributed)
+        trainer.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

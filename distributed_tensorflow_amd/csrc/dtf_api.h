@@ -105,7 +105,6 @@ int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t ro
 // --- one-shot gradient all-reduce + SGD apply over peer-mapped HBM (xgmi.hip) -----------------
 #define DTF_XGMI_MAX_RANKS 16
 int dtf_xgmi_max_ranks(void);
-int dtf_xgmi_table_entries(void);
 // Zero-filled device memory that other processes may map; uncached != 0 for words that one GPU
 // polls while another writes them.
 int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached);
@@ -113,10 +112,11 @@ int dtf_xgmi_free(void* p);
 int dtf_xgmi_export(void* p, void* handle64);
 int dtf_xgmi_open(const void* handle64, void** out);
 int dtf_xgmi_close(void* p);
-// params -= lr * sum over ranks of their gradient slab `slot`; global_step += 1.  See xgmi.hip.
-int dtf_xgmi_allreduce_apply(const uint64_t* table, int slot, const uint32_t* my_flags, float* params, int64_t n,
-                             const float* lr, float* global_step, uint32_t* state, int rank, int world,
-                             int timeout_ms, void* stream);
+// params -= lr * sum over ranks r of grads[r]; global_step += 1.  grads / peer_flags: HOST arrays of `world`
+// device addresses (own entries local, the others mapped).  See xgmi.hip.
+int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
+                             float* params, int64_t n, const float* lr, float* global_step, uint32_t* state,
+                             int rank, int world, int timeout_ms, void* stream);
 
 const char* dtf_hip_build_info(void);
 

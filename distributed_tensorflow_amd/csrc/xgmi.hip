@@ -36,100 +36,127 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxRanks = DTF_XGMI_MAX_RANKS;
 
-// Layout of the device-resident pointer table (uint64 entries).
-constexpr int kTabGrad0 = 0;                  // [rank] gradient slab of even exchanges
-constexpr int kTabGrad1 = kMaxRanks;          // [rank] gradient slab of odd exchanges
-constexpr int kTabFlags = 2 * kMaxRanks;      // [rank] base of that rank's arrival-flag array
 // state words
 constexpr int kSeq = 0, kDone = 1, kError = 2;
 
+// All pointers travel in the kernel arguments: with a compile-time replica count the compiler keeps
+// them in scalar registers and the kernel starts without a dependent table load.
 struct XgmiArgs {
-  const uint64_t* table;
+  const float* grad[kMaxRanks];      // [rank] gradient slab of this exchange's slot (own entry: local)
+  uint32_t* peer_flags[kMaxRanks];   // [rank] base of that rank's arrival-flag array
   const uint32_t* my_flags;
   float* params;
   int64_t n;
   const float* lr;
   float* global_step;
   uint32_t* state;
-  int slot, rank, world;
+  int rank, world;
   int64_t timeout_ticks;
 };
 
 template <int W>
-__device__ __forceinline__ void reduce_apply(const XgmiArgs& a, const float* const* grad, int world) {
-  const float lr = *a.lr;
-  const int64_t nvec = a.n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  f32x4* p4 = reinterpret_cast<f32x4*>(a.params);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-    f32x4 sum;
-    const f32x4 p = p4[i];
-    if (W > 0) {
-      f32x4 v[W > 0 ? W : 1];
+__device__ __forceinline__ const float* pick(const float* const (&tab)[kMaxRanks], int r, int world) {
+  const float* p = tab[0];
+  if (W > 0) {
 #pragma unroll
-      for (int r = 0; r < W; ++r) v[r] = reinterpret_cast<const f32x4*>(grad[r])[i];
-      sum = v[0];
-#pragma unroll
-      for (int r = 1; r < W; ++r) sum = sum + v[r];
-    } else {
-      sum = reinterpret_cast<const f32x4*>(grad[0])[i];
-      for (int r = 1; r < world; ++r) sum = sum + reinterpret_cast<const f32x4*>(grad[r])[i];
-    }
-    p4[i] = p - lr * sum;
+    for (int k = 1; k < W; ++k) p = (r == k) ? tab[k] : p;
+  } else {
+    for (int k = 1; k < world; ++k) p = (r == k) ? tab[k] : p;
   }
-  if (blockIdx.x == 0) {
-    const int64_t t = (nvec << 2) + threadIdx.x;
-    if (t < a.n) {
-      float sum = grad[0][t];
-      for (int r = 1; r < world; ++r) sum += grad[r][t];
-      a.params[t] -= lr * sum;
-    }
-    // thread 0 of block 0 also owns vector 0, so a global_step that lives inside the slab is
-    // updated after its (zero-gradient) SGD write, in program order
-    if (threadIdx.x == 0 && a.global_step) *a.global_step += 1.0f;
-  }
+  return p;
 }
 
 template <int W>
 __global__ __launch_bounds__(kBlock) void xgmi_allreduce_apply_kernel(XgmiArgs a) {
   __shared__ int failed;
-  __shared__ const float* grad[kMaxRanks];
   const int tid = threadIdx.x;
   const int world = W > 0 ? W : a.world;
   const uint32_t seq = __hip_atomic_load(&a.state[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t poisoned = __hip_atomic_load(&a.state[kError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) failed = poisoned ? 1 : 0;
-  if (tid < world) grad[tid] = reinterpret_cast<const float*>(a.table[(a.slot ? kTabGrad1 : kTabGrad0) + tid]);
+
+  // Local operands of this thread's first vector are requested before the wait: the parameters and the
+  // replica's own gradient (complete since the preceding kernel) do not depend on any peer.
+  const int64_t nvec = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t first = (int64_t)blockIdx.x * kBlock + tid;
+  f32x4* p4 = reinterpret_cast<f32x4*>(a.params);
+  const f32x4* own4 = reinterpret_cast<const f32x4*>(pick<W>(a.grad, a.rank, world));
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 p_first = zero, own_first = zero;
+  if (first < nvec) {
+    p_first = p4[first];
+    own_first = own4[first];
+  }
+  const float lr = *a.lr;
   __syncthreads();
 
   if (!poisoned) {
-    if (blockIdx.x == 0 && tid < world && tid != a.rank) {
-      uint32_t* theirs = reinterpret_cast<uint32_t*>(a.table[kTabFlags + tid]);
-      __hip_atomic_store(&theirs[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (tid < world && tid != a.rank) {
-      const long long t0 = wall_clock64();
-      while ((int32_t)(__hip_atomic_load(&a.my_flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-        if (wall_clock64() - t0 > a.timeout_ticks) {
-          failed = 1;
-          break;
+    if (world > 1) {
+      if (blockIdx.x == 0 && tid < world && tid != a.rank) {
+        uint32_t* theirs = a.peer_flags[0];
+        if (W > 0) {
+#pragma unroll
+          for (int k = 1; k < W; ++k) theirs = (tid == k) ? a.peer_flags[k] : theirs;
+        } else {
+          for (int k = 1; k < world; ++k) theirs = (tid == k) ? a.peer_flags[k] : theirs;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __hip_atomic_store(&theirs[a.rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      if (tid < world && tid != a.rank) {
+        const long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(&a.my_flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+          if (wall_clock64() - t0 > a.timeout_ticks) {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+      if (!failed) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: peers' slabs are read fresh
     }
-    __syncthreads();
     if (!failed) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: peers' slabs are read fresh
-      reduce_apply<W>(a, grad, world);
+      for (int64_t i = first; i < nvec; i += stride) {
+        const bool head = i == first;
+        const f32x4 p = head ? p_first : p4[i];
+        f32x4 sum;
+        if (W > 0) {
+          f32x4 v[W > 0 ? W : 1];
+#pragma unroll
+          for (int r = 0; r < W; ++r) {
+            if (r == a.rank) v[r] = head ? own_first : own4[i];
+            else v[r] = reinterpret_cast<const f32x4*>(a.grad[r])[i];
+          }
+          sum = v[0];
+#pragma unroll
+          for (int r = 1; r < W; ++r) sum = sum + v[r];     // rank order: identical bits on every replica
+        } else {
+          sum = reinterpret_cast<const f32x4*>(pick<0>(a.grad, 0, world))[i];
+          for (int r = 1; r < world; ++r) sum = sum + reinterpret_cast<const f32x4*>(pick<0>(a.grad, r, world))[i];
+        }
+        p4[i] = p - lr * sum;
+      }
+      if (blockIdx.x == 0) {
+        const int64_t t = (nvec << 2) + tid;
+        if (t < a.n) {
+          float sum = pick<W>(a.grad, 0, world)[t];
+          for (int r = 1; r < world; ++r) sum += pick<W>(a.grad, r, world)[t];
+          a.params[t] -= lr * sum;
+        }
+        // thread 0 of block 0 also owns vector 0, so a global_step that lives inside the slab is
+        // updated after its (zero-gradient) SGD write, in program order
+        if (tid == 0 && a.global_step) *a.global_step += 1.0f;
+      }
     }
   }
 
   __syncthreads();
   if (tid == 0) {
     if (failed && !poisoned) atomicExch(&a.state[kError], 1u);
-    __threadfence();
-    const uint32_t done = atomicAdd(&a.state[kDone], 1u);
-    if (done == gridDim.x - 1) {      // last block out: the next launch on this stream sees seq + 1
+    // Plain counting: the end of the kernel publishes everything to the next launch on this stream.
+    const uint32_t done = __hip_atomic_fetch_add(&a.state[kDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {      // last block out: the next launch sees seq + 1
       __hip_atomic_store(&a.state[kDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&a.state[kSeq], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -141,8 +168,6 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 extern "C" int dtf_xgmi_max_ranks(void) { return kMaxRanks; }
-
-extern "C" int dtf_xgmi_table_entries(void) { return 3 * kMaxRanks; }
 
 // Device memory that peers may map.  uncached != 0: fine-grained memory that no L2 keeps a copy
 // of, for words one GPU polls while another writes them.  The memory is zero-filled.
@@ -200,27 +225,28 @@ extern "C" int dtf_xgmi_close(void* p) {
   return hipIpcCloseMemHandle(p) == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
-// One exchange of replica `rank`: see the file header.  `table` is the device-resident pointer
-// table (dtf_xgmi_table_entries() uint64 words: even-step slabs, odd-step slabs, flag arrays, each
-// indexed by rank; the entries of `rank` itself are its local pointers), `slot` the parity of the
-// exchange the preceding backward wrote its gradient for, `state` three zero-initialised words in
-// local device memory whose first one must be set to 1 before the first exchange.
-extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* table, int slot, const uint32_t* my_flags, float* params,
-                                        int64_t n, const float* lr, float* global_step, uint32_t* state, int rank,
-                                        int world, int timeout_ms, void* stream) {
-  if (!table || !my_flags || !params || !lr || !state) return DTF_ERR_NULL;
-  if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world || n < 0 || (slot != 0 && slot != 1))
-    return DTF_ERR_SHAPE;
+// One exchange of replica `rank`: see the file header.  `grads[r]` is rank r's gradient slab of the slot
+// the preceding backward wrote (own entry: the local slab, others: their mappings), `peer_flags[r]` the
+// base of rank r's flag array, `state` three zero-initialised words in local device memory whose first
+// one must be set to 1 before the first exchange.
+extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
+                                        float* params, int64_t n, const float* lr, float* global_step,
+                                        uint32_t* state, int rank, int world, int timeout_ms, void* stream) {
+  if (!grads || !peer_flags || !my_flags || !params || !lr || !state) return DTF_ERR_NULL;
+  if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world || n < 0) return DTF_ERR_SHAPE;
   if (!aligned16(params)) return DTF_ERR_SHAPE;
   XgmiArgs a;
-  a.table = table;
+  for (int r = 0; r < kMaxRanks; ++r) {
+    a.grad[r] = r < world ? reinterpret_cast<const float*>(grads[r]) : nullptr;
+    a.peer_flags[r] = r < world ? reinterpret_cast<uint32_t*>(peer_flags[r]) : nullptr;
+    if (r < world && (!a.grad[r] || !a.peer_flags[r] || !aligned16(a.grad[r]))) return DTF_ERR_NULL;
+  }
   a.my_flags = my_flags;
   a.params = params;
   a.n = n;
   a.lr = lr;
   a.global_step = global_step;
   a.state = state;
-  a.slot = slot;
   a.rank = rank;
   a.world = world;
   a.timeout_ticks = (int64_t)(timeout_ms > 0 ? timeout_ms : 5000) * 100000;   // 100 MHz wall clock
@@ -230,6 +256,7 @@ extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* table, int slot, const u
   const dim3 grid((unsigned)blocks), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   switch (world) {
+    case 1: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<1>, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<2>, grid, block, 0, s, a); break;
     case 4: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<4>, grid, block, 0, s, a); break;
     case 8: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<8>, grid, block, 0, s, a); break;

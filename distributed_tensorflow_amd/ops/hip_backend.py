@@ -90,14 +90,13 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.dtf_hip_build_info.restype = C.c_char_p
     lib.dtf_xgmi_max_ranks.argtypes = []
-    lib.dtf_xgmi_table_entries.argtypes = []
     lib.dtf_xgmi_alloc.argtypes = [C.POINTER(C.c_void_p), i64, i32]
     lib.dtf_xgmi_free.argtypes = [vp]
     lib.dtf_xgmi_export.argtypes = [vp, C.c_char_p]
     lib.dtf_xgmi_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.dtf_xgmi_close.argtypes = [vp]
-    lib.dtf_xgmi_allreduce_apply.argtypes = [vp, i32, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
-    for name in ("dtf_xgmi_max_ranks", "dtf_xgmi_table_entries", "dtf_xgmi_alloc", "dtf_xgmi_free",
+    lib.dtf_xgmi_allreduce_apply.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
+    for name in ("dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
                  "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_debug_force_generic_path.argtypes = [i32]

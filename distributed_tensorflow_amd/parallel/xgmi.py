@@ -6,8 +6,8 @@ Every replica (one process per GPU, or several processes on one GPU in tests) ow
 * an array of arrival flags in uncached memory, one word per peer,
 * three words of local state (exchange number, finished blocks, error),
 
-exports the first two as HIP-IPC handles, maps those of every peer, and stores all the
-pointers in a small device table.  ``apply()`` then launches ONE kernel that announces the
+exports the first two as HIP-IPC handles and maps those of every peer; the addresses travel in the
+arguments of every launch.  ``apply()`` then launches ONE kernel that announces the
 local gradient, waits for the peers' announcements, sums the N slabs in rank order straight out
 of the peers' HBM and applies ``p -= lr * sum`` to the local replica of the variables.
 
@@ -58,7 +58,7 @@ def _open(handle: bytes) -> int:
 
 
 class XgmiExchange:
-    """Buffers, peer mappings and the pointer table of one replica.
+    """Buffers and peer mappings of one replica.
 
     ``numel``: floats per gradient slab (padded to a multiple of 4 internally).  ``group``: the
     ``torch.distributed`` group used to swap handles (None with ``world == 1`` or when the peers
@@ -87,7 +87,6 @@ class XgmiExchange:
             self.grads = [both[: self.padded][: self.numel], both[self.padded:][: self.numel]]
             self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
             self.state[0] = 1                                   # exchanges are numbered from 1; flags start at 0
-            self.table = torch.zeros(lib.dtf_xgmi_table_entries(), dtype=torch.int64, device=self.device)
         self._peer_grad = [0] * self.world
         self._peer_flag = [0] * self.world
         self._peer_grad[self.rank], self._peer_flag[self.rank] = self._grad_ptr, self._flag_ptr
@@ -130,14 +129,10 @@ class XgmiExchange:
         self._write_table()
 
     def _write_table(self):
-        m = self._max
-        host = [0] * (3 * m)
-        for r in range(self.world):
-            host[r] = self._peer_grad[r]
-            host[m + r] = self._peer_grad[r] + self.padded * 4
-            host[2 * m + r] = self._peer_flag[r]
-        self.table.copy_(torch.tensor(host, dtype=torch.int64))
-        torch.cuda.synchronize(self.device)
+        """Host arrays of device addresses handed to every launch: slabs of slot 0, slabs of slot 1, flag arrays."""
+        u64 = C.c_uint64 * self.world
+        self._slot_tabs = [u64(*self._peer_grad), u64(*[g + self.padded * 4 for g in self._peer_grad])]
+        self._flag_tab = u64(*self._peer_flag)
 
     # -- per step ----------------------------------------------------------------------
     def apply(self, params: torch.Tensor, lr: torch.Tensor, slot: int, global_step: Optional[torch.Tensor] = None):
@@ -145,7 +140,7 @@ class XgmiExchange:
         if params.numel() != self.numel:
             raise ValueError("parameter slab and gradient slabs differ in size")
         hb._check(hb.require().dtf_xgmi_allreduce_apply(
-            self.table.data_ptr(), int(slot) & 1, self._flag_ptr, params.data_ptr(), self.numel, lr.data_ptr(),
+            self._slot_tabs[int(slot) & 1], self._flag_tab, self._flag_ptr, params.data_ptr(), self.numel, lr.data_ptr(),
             None if global_step is None else global_step.data_ptr(), self.state.data_ptr(), self.rank, self.world,
             self.timeout_ms, torch.cuda.current_stream(self.device).cuda_stream), "dtf_xgmi_allreduce_apply")
 

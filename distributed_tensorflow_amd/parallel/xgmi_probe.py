@@ -1,0 +1,92 @@
+"""Trial run of the peer-mapped gradient exchange in a process of its own.
+
+``bench.py`` (and anything else that wants the one-kernel exchange on a node it has never run on)
+starts one of these per rank BEFORE it touches the GPU itself::
+
+    python -m distributed_tensorflow_amd.parallel.xgmi_probe --rank R --world N --device D --port P
+
+The replicas rendezvous over gloo on 127.0.0.1:P, map each other's buffers, train a few hundred
+steps and then check what matters: no exchange timed out, every replica holds bit-identical
+variables (the sums are taken in rank order, so anything else means a peer's gradient was read
+stale or torn), and the variables moved.  One JSON line reports ``ok`` and the time per step; the
+exit code is 0 only when ``ok``.  A crash, a hang (the caller's timeout) or a disagreement costs the
+caller nothing but the fallback to the library collectives.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--chunk", type=int, default=50)
+    ap.add_argument("--rows", type=int, default=5500)
+    ap.add_argument("--uncached", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+
+    from ..data import DeviceDataset
+    from .replicas import build_replica_trainer
+
+    out = {"ok": False, "rank": args.rank, "world": args.world}
+
+    def note(msg):
+        print(f"[peer-exchange trial {args.rank}/{args.world}] {msg}", file=sys.stderr, flush=True)
+
+    try:
+        dist.init_process_group("gloo", rank=args.rank, world_size=args.world,
+                                init_method=f"tcp://127.0.0.1:{args.port}")
+        dev = torch.device("cuda", args.device)
+        torch.cuda.set_device(dev)
+        g = torch.Generator().manual_seed(4242 + args.rank)
+        x = torch.rand(args.rows, 784, generator=g)
+        y = torch.eye(10)[torch.randint(0, 10, (args.rows,), generator=g)]
+        ds = DeviceDataset(x, y, dev, 100, seed=1000 + args.rank)
+        t = build_replica_trainer("xgmi", device=dev, dataset=ds, batch=100, lr=0.001, seed=1, rank=args.rank,
+                                  world=args.world, chunk=args.chunk, use_graph=True,
+                                  uncached_grads=bool(args.uncached), timeout_ms=10000)
+        note("buffers mapped")
+        p0 = t.params.clone()
+        t.prepare((args.steps, args.steps))
+        note("graphs captured")
+        dist.barrier()
+        t.run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        note("warm-up steps done")
+        dist.barrier()
+        t0 = time.perf_counter()
+        t.run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        healthy = t.healthy()
+        sums = [None] * args.world
+        dist.all_gather_object(sums, (t.replica_checksum(), healthy, dt))
+        moved = float((t.params - p0)[4:].abs().max())
+        finite = bool(torch.isfinite(t.params).all())
+        out.update(healthy=all(s[1] for s in sums), identical=len({s[0] for s in sums}) == 1, moved=moved,
+                   finite=finite, ms_per_step=round(1000.0 * max(s[2] for s in sums) / args.steps, 5),
+                   global_step=t.global_step_value(), exchanges=t.xg.exchanges_done())
+        out["ok"] = bool(out["healthy"] and out["identical"] and finite and moved > 0.0
+                         and out["global_step"] == 2 * args.steps)
+        note(f"ok={out['ok']} {out['ms_per_step']} ms/step")
+        dist.barrier()
+        t.close()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001 — every failure is an answer: "do not use this path here"
+        out["error"] = f"{type(e).__name__}: {e}"
+    print(json.dumps(out), flush=True)
+    return 0 if out["ok"] else 3
+
+
+if __name__ == "__main__":
+    sys.exit(main())

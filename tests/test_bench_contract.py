@@ -53,3 +53,23 @@ def test_gpus_flag_must_match_the_world_size():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu", "--steps", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "torch.distributed.run" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
+    """Trial in child processes -> probe of the candidates -> timed run -> replica agreement check.
+    RCCL refuses two ranks on one device, so the rehearsal's rendezvous is gloo (DTF_BENCH_SHARE_GPU=1)."""
+    port = free_ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "600", "--warmup", "100"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=380,
+                       env=dict(os.environ, DTF_BENCH_SHARE_GPU="1"))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    doc = json.loads([line for line in p.stdout.splitlines() if line.startswith("{")][-1])
+    assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 200
+    assert doc["peer_exchange_trial"]["ok"] is True and doc["peer_exchange_trial"]["identical"] is True
+    assert set(doc["mode_probe_ms_per_step"]) == {"xgmi"}
+    assert "peer-mapped" in doc["config"]["parallelism"]
+    assert doc["global_step"] >= 700
