@@ -117,6 +117,11 @@ int dtf_xgmi_close(void* p);
 int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
                              float* params, int64_t n, const float* lr, float* global_step, uint32_t* state,
                              int rank, int world, int timeout_ms, void* stream);
+// One-sided asynchronous PS traffic over the same mappings: the slab is cut into `world` shards of `chunk`
+// floats, shard k authoritative in rank k's buffer (shards[k], slab-sized).  See xgmi.hip.
+int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local, void* stream);
+int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const float* grad, const float* lr,
+                      int64_t step_index, void* stream);
 
 const char* dtf_hip_build_info(void);
 

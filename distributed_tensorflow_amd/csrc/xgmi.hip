@@ -163,6 +163,62 @@ __global__ __launch_bounds__(kBlock) void xgmi_allreduce_apply_kernel(XgmiArgs a
   }
 }
 
+// ---- asynchronous parameter-server traffic over the same mappings ---------------------------------
+// The variables are one flat slab cut into `world` equal shards; shard k's authoritative copy lives in
+// rank k's HBM (inside a buffer as large as the whole slab, so an element has the same index everywhere).
+//   pull : local[i] = shard_owner(i)[i]            one launch reads every shard, remote ones over xGMI
+//   push : shard_owner(i)[i] -= lr * grad[i]       one launch updates every shard IN PLACE, one-sided and
+//          lock-free: concurrent workers interleave (and may lose) updates, the meaning of
+//          use_locking=False in the reference (tfdist_between.py:65); global_step += 1 atomically.
+// No worker waits for any other: there is no flag, no barrier and no matching receive.
+struct ShardArgs {
+  float* shard[kMaxRanks];
+  int64_t chunk;        // floats per shard, a multiple of 4
+  int64_t n;            // floats in the slab, world * chunk
+  int world;
+};
+
+__device__ __forceinline__ float* shard_of(const ShardArgs& a, int owner) {
+  float* p = a.shard[0];
+  for (int k = 1; k < a.world; ++k) p = (owner == k) ? a.shard[k] : p;
+  return p;
+}
+
+__global__ __launch_bounds__(kBlock) void shard_pull_kernel(ShardArgs a, float* __restrict__ local) {
+  const int64_t nvec = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  f32x4* l4 = reinterpret_cast<f32x4*>(local);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    const int owner = (int)((i << 2) / a.chunk);
+    l4[i] = reinterpret_cast<const f32x4*>(shard_of(a, owner))[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void shard_push_sgd_kernel(ShardArgs a, const float* __restrict__ grad,
+                                                                const float* __restrict__ lr_ptr, int64_t step_index) {
+  const float lr = *lr_ptr;
+  const int64_t nvec = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(grad);
+  const int64_t step_vec = step_index >= 0 ? (step_index >> 2) : -1;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    const int owner = (int)((i << 2) / a.chunk);
+    float* dst = shard_of(a, owner);
+    const f32x4 g = g4[i];
+    if (i != step_vec) {
+      f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+      d4[i] = d4[i] - lr * g;
+    } else {
+      // the vector that holds global_step: the counter is only ever touched by the atomic below
+      for (int c = 0; c < 4; ++c) {
+        const int64_t e = (i << 2) + c;
+        if (e != step_index) dst[e] -= lr * g[c];
+      }
+      __hip_atomic_fetch_add(dst + step_index, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -262,5 +318,50 @@ extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* p
     case 8: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<8>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<0>, grid, block, 0, s, a); break;
   }
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+static int fill_shards(ShardArgs& a, const uint64_t* shards, int world, int64_t chunk) {
+  if (!shards) return DTF_ERR_NULL;
+  if (world < 1 || world > kMaxRanks || chunk <= 0 || (chunk & 3)) return DTF_ERR_SHAPE;
+  for (int r = 0; r < kMaxRanks; ++r) {
+    a.shard[r] = r < world ? reinterpret_cast<float*>(shards[r]) : nullptr;
+    if (r < world && (!a.shard[r] || !aligned16(a.shard[r]))) return DTF_ERR_NULL;
+  }
+  a.chunk = chunk;
+  a.n = chunk * world;
+  a.world = world;
+  return DTF_OK;
+}
+
+static dim3 shard_grid(int64_t n) {
+  int64_t blocks = ((n >> 2) + kBlock - 1) / kBlock;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  return dim3((unsigned)blocks);
+}
+
+// local[0 .. world*chunk) = the authoritative copy of every shard.  shards: HOST array of `world` device
+// addresses, entry k = base of rank k's slab-sized buffer (own entry local, the others mapped).
+extern "C" int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local, void* stream) {
+  ShardArgs a;
+  const int rc = fill_shards(a, shards, world, chunk);
+  if (rc != DTF_OK) return rc;
+  if (!local || !aligned16(local)) return DTF_ERR_NULL;
+  hipLaunchKernelGGL(shard_pull_kernel, shard_grid(a.n), dim3(kBlock), 0, (hipStream_t)stream, a, local);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// Every shard -= lr * (its range of grad), written through the mappings; step_index >= 0: the element
+// that holds global_step, which is incremented atomically instead (its gradient is ignored).
+extern "C" int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const float* grad,
+                                 const float* lr, int64_t step_index, void* stream) {
+  ShardArgs a;
+  const int rc = fill_shards(a, shards, world, chunk);
+  if (rc != DTF_OK) return rc;
+  if (!grad || !lr || !aligned16(grad)) return DTF_ERR_NULL;
+  if (step_index >= a.n) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(shard_push_sgd_kernel, shard_grid(a.n), dim3(kBlock), 0, (hipStream_t)stream, a, grad, lr,
+                     step_index);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }

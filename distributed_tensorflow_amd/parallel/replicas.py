@@ -397,9 +397,84 @@ class XgmiTowerTrainer(_BaseTrainer):
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
 
+class XgmiAsyncTrainer(_BaseTrainer):
+    """Between-graph ASYNCHRONOUS workers on N GPUs with GPU-resident PS shards reached one-sidedly.
+
+    Rank r is worker r and owns PS shard r (``parallel/xgmi.py::PeerShards``).  A step is
+
+        pull   every shard -> private slab        (1 launch, remote shards over xGMI)
+        fwd + bwd on the worker's own mini-batch   (2 launches)
+        push   shard -= lr * g on every shard      (1 launch, in place through the mappings, global_step += 1)
+
+    with no barrier, flag or matching receive anywhere: workers run at their own pace against whatever the
+    shards hold when they pull, and concurrent pushes interleave without a lock — the reference's default
+    (GradientDescentOptimizer, use_locking=False, tfdist_between.py:65-66).  ``global_step`` counts every
+    worker's push, so it advances by N per "round" (README.md:70-72 of the reference observes the same).
+    """
+
+    name = "xgmi_async"
+
+    def __init__(self, *a, group=None, **kw):
+        super().__init__(*a, **kw)
+        if self.device.type != "cuda":
+            raise RuntimeError("the peer-mapped shards are a GPU path")
+        from .xgmi import PeerShards
+
+        self.group = group
+        chunk = self.layout.shard_numel(0)
+        self.shards = PeerShards(self.rank, self.world, chunk, self.device, group=group)
+        if self.shards.total != self.params.numel():
+            raise RuntimeError("layout and shard sizes disagree")
+        self.shards.publish(self.params)          # same seed everywhere: every rank publishes its own range
+        self.step_index = self.layout.var_range["global_step"][0]
+        # load every kernel of the step outside any capture without changing a shard (lr = 0, no count)
+        zero_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.shards.pull(self.params)
+        self.engine.step_grad(0, 1.0)
+        self.shards.push_sgd(self.grads, zero_lr, -1)
+        torch.cuda.synchronize(self.device)
+        self.engine.reset_step_workspace(0)
+
+    def _one_step(self, batch_index: int):
+        with span("pull"):
+            self.shards.pull(self.params)
+        with span("step"):
+            self.engine.step_grad(batch_index, 1.0)
+        with span("push_apply"):
+            self.shards.push_sgd(self.grads, self.lr, self.step_index)
+
+    def _capture(self, pos: int, n: int, parity: int):
+        # No warm-up replay: a step writes the shared shards, which cannot be rolled back.
+        self.engine.reset_step_workspace(parity)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for i in range(n):
+                self._one_step(pos + i)
+        self.engine.parity = parity
+        return graph
+
+    def evaluate(self, x, y):
+        self.shards.pull(self.params)
+        return self.engine.evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        self.shards.pull(self.params)
+        return int(round(float(self.global_step.item())))
+
+    def close(self):
+        self._graphs.clear()
+        self.shards.close()
+
+    def describe(self):
+        return (f"async PS dp{self.world}: shard per GPU in HBM, one-sided pull (1 launch) -> 2 launches -> "
+                f"one-sided lock-free SGD push (1 launch) through peer mappings, no barrier"
+                + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
+
+
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer}[mode]
+           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi_async": XgmiAsyncTrainer}[mode]
     if mode == "single" and kw.get("world", 1) != 1:
         raise ValueError("single mode is one process")
     return cls(**kw)

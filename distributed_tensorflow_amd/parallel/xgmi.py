@@ -172,3 +172,101 @@ class XgmiExchange:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class PeerShards:
+    """GPU-resident parameter-server shards that every worker reaches one-sidedly (asynchronous mode).
+
+    The variables are one flat slab of ``world * chunk`` floats; shard *k* (elements ``[k*chunk, (k+1)*chunk)``)
+    is authoritative in rank *k*'s buffer.  Every rank allocates a slab-sized buffer, exports it and maps the
+    others, after which
+
+    * ``pull(local)``      copies every shard into the worker's private slab — one launch, remote shards
+      read over xGMI;
+    * ``push_sgd(g, lr)``  applies ``shard -= lr * g`` to every shard in place through the mappings and bumps
+      ``global_step`` atomically — one launch, lock-free (``use_locking=False``, tfdist_between.py:65).
+
+    Nothing here waits for another worker.
+    """
+
+    def __init__(self, rank: int, world: int, chunk: int, device: torch.device, group=None):
+        lib = hb.require()
+        if not 1 <= world <= lib.dtf_xgmi_max_ranks():
+            raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
+        if chunk <= 0 or chunk % 4:
+            raise ValueError("shards must be a positive multiple of 4 floats")
+        self.rank, self.world, self.chunk, self.device = int(rank), int(world), int(chunk), torch.device(device)
+        self.total = self.chunk * self.world
+        self._closed = False
+        self._mapped: List[int] = []
+        with torch.cuda.device(self.device):
+            self._ptr = _alloc(self.total * 4, False)
+            self._buf = _DeviceBuffer(self._ptr, self.total * 4, "<f4", 4, True)
+            self.buffer = torch.as_tensor(self._buf, device=self.device)
+        ptrs = [0] * self.world
+        ptrs[self.rank] = self._ptr
+        if self.world > 1:
+            import torch.distributed as dist
+
+            everyone: List[Optional[dict]] = [None] * self.world
+            dist.all_gather_object(everyone, {"rank": self.rank, "handle": _export(self._ptr), "total": self.total},
+                                   group=group)
+            with torch.cuda.device(self.device):
+                for h in everyone:
+                    if h["rank"] == self.rank:
+                        continue
+                    if h["total"] != self.total:
+                        raise RuntimeError("workers disagree on the slab size")
+                    ptrs[h["rank"]] = _open(h["handle"])
+                    self._mapped.append(ptrs[h["rank"]])
+        self._tab = (C.c_uint64 * self.world)(*ptrs)
+        self._group = group
+
+    @property
+    def my_shard(self) -> torch.Tensor:
+        return self.buffer[self.rank * self.chunk:(self.rank + 1) * self.chunk]
+
+    def publish(self, slab: torch.Tensor):
+        """Initialise this rank's shard from its range of ``slab``; returns once every rank has done so."""
+        a = self.rank * self.chunk
+        self.my_shard.copy_(slab[a:a + self.chunk])
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier(group=self._group)
+
+    def pull(self, local: torch.Tensor):
+        if local.numel() != self.total:
+            raise ValueError("local slab size differs from the sharded slab")
+        hb._check(hb.require().dtf_xgmi_pull(self._tab, self.world, self.chunk, local.data_ptr(),
+                                             torch.cuda.current_stream(self.device).cuda_stream), "dtf_xgmi_pull")
+
+    def push_sgd(self, grads: torch.Tensor, lr: torch.Tensor, step_index: int = -1):
+        if grads.numel() != self.total:
+            raise ValueError("gradient slab size differs from the sharded slab")
+        hb._check(hb.require().dtf_xgmi_push_sgd(self._tab, self.world, self.chunk, grads.data_ptr(), lr.data_ptr(),
+                                                 int(step_index),
+                                                 torch.cuda.current_stream(self.device).cuda_stream),
+                  "dtf_xgmi_push_sgd")
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        lib = hb.require()
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:  # noqa: BLE001 — tearing down after a device error
+            pass
+        with torch.cuda.device(self.device):
+            for p in self._mapped:
+                lib.dtf_xgmi_close(p)
+            self.buffer = None
+            lib.dtf_xgmi_free(self._ptr)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -1,7 +1,8 @@
 """One replica of the peer-mapped exchange test (several of these share the GPU).
 
-usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED
-Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference.
+usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|async]
+Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference
+(sync), or the state of the shared shards after every worker finished (async).
 """
 import json
 import os
@@ -17,8 +18,34 @@ from distributed_tensorflow_amd.ops import reference as ref         # noqa: E402
 from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer  # noqa: E402
 
 
+def run_async(rank, world, steps, use_graph, dev, ds, B, lr):
+    t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
+                              chunk=3, use_graph=bool(use_graph))
+    p0 = t.params.clone()
+    loss0, _ = t.evaluate(ds.x_epoch, ds.y_epoch)
+    t.prepare((steps,))
+    dist.barrier()
+    t.run_steps(steps)
+    torch.cuda.synchronize()
+    dist.barrier()                       # every worker's pushes have landed
+    gs = t.global_step_value()           # pulls the shards
+    loss1, _ = t.evaluate(ds.x_epoch, ds.y_epoch)
+    mine = {"params": t.params.cpu(), "gs": gs}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    identical = all(torch.equal(e["params"], everyone[0]["params"]) for e in everyone)
+    moved = float((t.params - p0)[4:].abs().max())
+    finite = bool(torch.isfinite(t.params).all())
+    dist.barrier()
+    t.close()
+    print(json.dumps({"rank": rank, "identical": identical, "finite": finite, "moved": moved, "global_step": gs,
+                      "loss_before": loss0, "loss_after": loss1, "describe": t.describe()}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port, steps, use_graph, uncached = (int(v) for v in sys.argv[1:7])
+    mode = sys.argv[7] if len(sys.argv) > 7 else "sync"
     dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -27,6 +54,8 @@ def main():
     x = torch.rand(rows, 784, generator=g)
     y = torch.eye(10)[torch.randint(0, 10, (rows,), generator=g)]
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
+    if mode == "async":
+        return run_async(rank, world, steps, use_graph, dev, ds, B, lr)
     t = build_replica_trainer("xgmi", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
                               chunk=3, use_graph=bool(use_graph), uncached_grads=bool(uncached), timeout_ms=30000)
     p0 = t.params.clone().cpu()

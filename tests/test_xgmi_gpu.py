@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_replicas(world, steps, use_graph, uncached=0, timeout=150):
+def _run_replicas(world, steps, use_graph, uncached=0, timeout=150, mode="sync"):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_xgmi_worker.py"), str(r), str(world), str(port),
-                               str(steps), str(int(use_graph)), str(int(uncached))],
+                               str(steps), str(int(use_graph)), str(int(uncached)), mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = []
@@ -55,3 +55,16 @@ def test_replicas_stay_bit_identical_and_track_the_mean_gradient_reference(world
         assert r["moved"] > 1e-3                                   # the run did train
         assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r      # fp32 reference, different summation order
         assert "peer-mapped" in r["describe"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,use_graph", [(2, False), (3, True)])
+def test_async_workers_update_shared_shards_one_sidedly(world, use_graph):
+    steps = 8
+    res = _run_replicas(world, steps, use_graph, mode="async")
+    for r in res:
+        assert r["finite"] and r["identical"], r              # after the last push everybody pulls the same shards
+        assert r["global_step"] == world * steps, r           # every push counted, atomically
+        assert r["moved"] > 1e-3 and r["loss_after"] < r["loss_before"], r
+        assert "one-sided" in r["describe"]
