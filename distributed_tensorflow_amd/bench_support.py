@@ -107,11 +107,12 @@ def run_benchmark(args) -> Optional[dict]:
     if distributed:
         lib_backend = not (use_cpu or share_gpu)
         dist.init_process_group(backend="nccl" if lib_backend else "gloo", device_id=device if lib_backend else None)
-    xgmi_ok = False
+    xgmi_ok = peer_async_ok = False
     if trial is not None:
-        flag = torch.tensor([1 if trial.get("ok") else 0], dtype=torch.int32, device=device)
+        flag = torch.tensor([1 if trial.get("ok") else 0, 1 if trial.get("async_ok") else 0], dtype=torch.int32,
+                            device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        xgmi_ok = bool(int(flag.item()))
+        xgmi_ok, peer_async_ok = bool(int(flag[0].item())), bool(int(flag[1].item()))
         if rank == 0 and not xgmi_ok:
             print(f"[bench] peer-mapped exchange not used on this node: {trial}", flush=True)
 
@@ -123,7 +124,7 @@ def run_benchmark(args) -> Optional[dict]:
 
     def build(m):
         # gloo collectives (the one-GPU rehearsal) cannot be captured; the peer-mapped exchange can
-        graph = not args.no_graph and not (share_gpu and m != "xgmi")
+        graph = not args.no_graph and not (share_gpu and m not in ("xgmi", "xgmi_async"))
         extra = {"uncached_grads": bool(trial and trial.get("uncached_grads"))} if m == "xgmi" else {}
         return build_replica_trainer(mode=m, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
                                      rank=rank, world=world, chunk=int(args.chunk), use_graph=graph, **extra)
@@ -229,6 +230,37 @@ def run_benchmark(args) -> Optional[dict]:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The asynchronous mode next to the headline (synchronous / single) number: between-graph workers that
+    # pull and push one-sidedly against GPU-resident shards (parallel/replicas.py::XgmiAsyncTrainer).  One
+    # process needs no peer; several use the peer mappings only after their trial run succeeded on this node.
+    async_report = None
+    if not use_cpu and (not distributed or peer_async_ok) and mode != "xgmi_async" \
+            and os.environ.get("DTF_BENCH_ASYNC", "1") != "0":
+        try:
+            a_steps = min(steps, 4 * STEPS_PER_EPOCH)
+            ta = build("xgmi_async")
+            prepare(ta, (warmup, a_steps))
+            ta.run_steps(warmup)
+            _sync(device, distributed)
+            ta0 = time.perf_counter()
+            ta.run_steps(a_steps)
+            _sync(device, distributed)
+            a_el = torch.tensor([time.perf_counter() - ta0], dtype=torch.float64, device=device)
+            if distributed:
+                dist.all_reduce(a_el, op=dist.ReduceOp.MAX)
+            a_el = float(a_el.item())
+            a_gs = ta.global_step_value()
+            a_loss, a_acc = ta.evaluate(torch.as_tensor(mnist.test.images).to(device),
+                                        torch.as_tensor(mnist.test.labels).to(device))
+            async_report = {"value": round(n * BATCH * a_steps / a_el, 1), "unit": "samples/s",
+                            "ms_per_step": round(1000.0 * a_el / a_steps, 5), "steps": a_steps,
+                            "global_step": a_gs, "every_push_counted": a_gs == n * (warmup + a_steps),
+                            "test_accuracy_after_run": round(a_acc, 4), "test_loss_after_run": round(a_loss, 4),
+                            "parallelism": ta.describe()}
+            retire(ta)
+        except Exception as e:  # noqa: BLE001 — the extra measurement must never cost the headline one
+            async_report = {"error": f"{type(e).__name__}: {e}"}
+
     test_x = torch.as_tensor(mnist.test.images).to(device)
     test_y = torch.as_tensor(mnist.test.labels).to(device)
     loss, acc = trainer.evaluate(test_x, test_y)
@@ -285,8 +317,11 @@ def run_benchmark(args) -> Optional[dict]:
         }
         if probe_ms is not None:
             result["mode_probe_ms_per_step"] = probe_ms
+        if async_report is not None:
+            result["async_mode"] = async_report
         if trial is not None:
-            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "error")
+            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok",
+                                                       "async_ms_per_step", "error")
                                              if k in trial}
     if hasattr(trainer, "close"):
         _sync(device, distributed)

@@ -8,8 +8,10 @@ starts one of these per rank BEFORE it touches the GPU itself::
 The replicas rendezvous over gloo on 127.0.0.1:P, map each other's buffers, train a few hundred
 steps and then check what matters: no exchange timed out, every replica holds bit-identical
 variables (the sums are taken in rank order, so anything else means a peer's gradient was read
-stale or torn), and the variables moved.  One JSON line reports ``ok`` and the time per step; the
-exit code is 0 only when ``ok``.  A crash, a hang (the caller's timeout) or a disagreement costs the
+stale or torn), and the variables moved.  The asynchronous mode (one-sided pulls and lock-free pushes on
+shards in the peers' HBM) is tried the same way: finite variables, every push counted in ``global_step``, a
+loss that went down.  One JSON line reports ``ok`` / ``async_ok`` and the times per step; the exit code is 0
+only when ``ok``.  A crash, a hang (the caller's timeout) or a disagreement costs the
 caller nothing but the fallback to the library collectives.
 """
 from __future__ import annotations
@@ -81,6 +83,31 @@ def main(argv=None) -> int:
         note(f"ok={out['ok']} {out['ms_per_step']} ms/step")
         dist.barrier()
         t.close()
+        # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes
+        ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
+                                   rank=args.rank, world=args.world, chunk=args.chunk, use_graph=True)
+        loss0, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
+        ta.prepare((args.steps, args.steps))
+        dist.barrier()
+        ta.run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        ta.run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        dta = time.perf_counter() - t0
+        dist.barrier()                                    # every worker's pushes have landed
+        gs = ta.global_step_value()
+        loss1, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
+        a_fin = bool(torch.isfinite(ta.params).all())
+        times = [None] * args.world
+        dist.all_gather_object(times, (dta, a_fin and gs == 2 * args.steps * args.world and loss1 <= loss0))
+        out.update(async_ok=all(x[1] for x in times), async_global_step=gs,
+                   async_ms_per_step=round(1000.0 * max(x[0] for x in times) / args.steps, 5),
+                   async_loss=[round(loss0, 4), round(loss1, 4)])
+        note(f"async ok={out['async_ok']} {out['async_ms_per_step']} ms/step")
+        dist.barrier()
+        ta.close()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer: "do not use this path here"
         out["error"] = f"{type(e).__name__}: {e}"
