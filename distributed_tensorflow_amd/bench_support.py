@@ -40,6 +40,8 @@ def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int) -> dict:
     import subprocess
 
     port = int(os.environ.get("MASTER_PORT", "29500")) + 37
+    if port > 65000:
+        port -= 1000
     cmd = [sys.executable, "-m", "distributed_tensorflow_amd.parallel.xgmi_probe", "--rank", str(rank),
            "--world", str(world), "--device", str(local_rank), "--port", str(port), "--chunk", str(chunk)]
     env = dict(os.environ)
