@@ -23,7 +23,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -51,8 +50,6 @@ def parse_args():
 
 def main():
     args = parse_args()
-    import torch
-
     from distributed_tensorflow_amd.bench_support import run_benchmark
 
     result = run_benchmark(args)

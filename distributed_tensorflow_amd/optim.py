@@ -31,7 +31,7 @@ from __future__ import annotations
 
 import threading
 import time
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence
 
 from . import graph as G
 from .utils.trace import span

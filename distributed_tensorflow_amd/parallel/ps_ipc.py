@@ -37,7 +37,6 @@ from __future__ import annotations
 
 import pickle
 import struct
-import threading
 import time
 from typing import List, Optional
 

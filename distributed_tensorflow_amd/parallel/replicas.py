@@ -26,8 +26,7 @@ one fused slab per collective, never one call per variable.
 """
 from __future__ import annotations
 
-import os
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

@@ -16,7 +16,6 @@ split by the round-robin placement (2 PS: 4,044 B to ps0, 314,000 B to ps1).
 from __future__ import annotations
 
 import struct
-import time
 from typing import List, Optional
 
 import numpy as np

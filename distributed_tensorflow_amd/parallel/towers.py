@@ -19,7 +19,7 @@ reduce through a plain sum instead of RCCL.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
 

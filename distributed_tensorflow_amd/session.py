@@ -34,10 +34,9 @@ from . import graph as G
 from .cluster import ConfigProto, lookup_server
 from .utils.trace import Collector, span
 from .models.mlp import MLPEngine
-from .ops import hip_backend as hb
 from .optim import Optimizer, SyncReplicasOptimizer
 from .parallel.store import LocalVariableStore, RemoteVariableStore
-from .placement import DeviceSpec, placement_report
+from .placement import DeviceSpec
 from .summary import Summary
 from .variables import ShardLayout
 

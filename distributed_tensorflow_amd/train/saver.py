@@ -17,7 +17,6 @@ from __future__ import annotations
 import os
 import re
 import struct
-import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np

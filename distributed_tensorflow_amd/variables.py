@@ -24,7 +24,7 @@ slabs; *placement* decides which PS shard owns which slab range.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch

@@ -3,7 +3,6 @@ import os
 import socket
 import subprocess
 import sys
-from contextlib import contextmanager
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

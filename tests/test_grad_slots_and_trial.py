@@ -1,6 +1,4 @@
 """CPU-side pieces of the peer-mapped exchange: gradient slots of the engine, and a trial that cannot run."""
-import argparse
-
 import torch
 
 from distributed_tensorflow_amd import bench_support

@@ -1,5 +1,4 @@
 """Placement and variable layout (round-robin order reproduces the reference's mapping)."""
-import numpy as np
 import pytest
 import torch
 
