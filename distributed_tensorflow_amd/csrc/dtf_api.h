@@ -105,6 +105,8 @@ int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t ro
 // --- one-shot gradient all-reduce + SGD apply over peer-mapped HBM (xgmi.hip) -----------------
 #define DTF_XGMI_MAX_RANKS 16
 int dtf_xgmi_max_ranks(void);
+// Kernels on `dev` may dereference memory of `peer` afterwards (DTF_ERR_UNSUPPORTED: no direct path).
+int dtf_enable_peer_access(int dev, int peer);
 // Zero-filled device memory that other processes may map; uncached != 0 for words that one GPU
 // polls while another writes them.
 int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached);

@@ -225,6 +225,25 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int dtf_xgmi_max_ranks(void) { return kMaxRanks; }
 
+// Let kernels launched on device `dev` dereference memory that lives on device `peer` (a shard mapped from a
+// ps task on another GPU).  Already-enabled access is success; the current device is restored.
+extern "C" int dtf_enable_peer_access(int dev, int peer) {
+  if (dev == peer) return DTF_OK;
+  int count = 0, current = 0, can = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || peer < 0 || dev >= count || peer >= count)
+    return DTF_ERR_SHAPE;
+  if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) {
+    (void)hipGetLastError();
+    return DTF_ERR_UNSUPPORTED;
+  }
+  (void)hipGetDevice(&current);
+  if (hipSetDevice(dev) != hipSuccess) return DTF_ERR_LAUNCH;
+  const hipError_t rc = hipDeviceEnablePeerAccess(peer, 0);
+  (void)hipGetLastError();
+  (void)hipSetDevice(current);
+  return (rc == hipSuccess || rc == hipErrorPeerAccessAlreadyEnabled) ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
 // Device memory that peers may map.  uncached != 0: fine-grained memory that no L2 keeps a copy
 // of, for words one GPU polls while another writes them.  The memory is zero-filled.
 extern "C" int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached) {

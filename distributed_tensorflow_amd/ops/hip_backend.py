@@ -96,6 +96,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.dtf_xgmi_close.argtypes = [vp]
     lib.dtf_xgmi_allreduce_apply.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
+    lib.dtf_enable_peer_access.argtypes = [i32, i32]
+    lib.dtf_enable_peer_access.restype = C.c_int
     lib.dtf_xgmi_pull.argtypes = [vp, i32, i64, vp, vp]
     lib.dtf_xgmi_push_sgd.argtypes = [vp, i32, i64, vp, vp, i64, vp]
     for name in ("dtf_xgmi_pull", "dtf_xgmi_push_sgd", "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
@@ -294,6 +296,16 @@ def mlp_step_grad(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: f
 
 def advance_cursor(cursor: torch.Tensor, n: int):
     _check(require().dtf_advance_cursor(_ptr(cursor), int(n), _stream()), "dtf_advance_cursor")
+
+
+def enable_peer_access(device: torch.device, peer: torch.device) -> None:
+    """Kernels launched on ``device`` may dereference tensors that live on ``peer`` afterwards."""
+    if device.type != "cuda" or peer.type != "cuda":
+        return
+    a = device.index if device.index is not None else torch.cuda.current_device()
+    b = peer.index if peer.index is not None else torch.cuda.current_device()
+    if a != b:
+        _check(require().dtf_enable_peer_access(int(a), int(b)), f"peer access cuda:{a} -> cuda:{b}")
 
 
 def build_info() -> str:

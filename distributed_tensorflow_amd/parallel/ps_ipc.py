@@ -143,6 +143,8 @@ class IpcVariableStore:
         if m is None:
             blob = self._c(k).get(HANDLE_KEY, timeout=self.timeout)
             m = _import(blob)
+            # a shard in another GPU's HBM: the worker's kernels (SGD push, initialisers) write through it
+            hb.enable_peer_access(self.device, m.device)
             self._maps[k] = m
         return m
 
