@@ -43,7 +43,8 @@ def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int) -> dict:
     if port > 65000:
         port -= 1000
     cmd = [sys.executable, "-m", "distributed_tensorflow_amd.parallel.xgmi_probe", "--rank", str(rank),
-           "--world", str(world), "--device", str(local_rank), "--port", str(port), "--chunk", str(chunk)]
+           "--world", str(world), "--device", str(local_rank), "--port", str(port), "--chunk", str(chunk),
+           "--rows", "55000", "--steps", str(STEPS_PER_EPOCH)]
     env = dict(os.environ)
     env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
     # The child makes a rendezvous of its own: nothing of the launcher's may leak into it (with
@@ -53,6 +54,7 @@ def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int) -> dict:
                                                   "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
                                                   "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
             env.pop(k)
+
     def attempt(extra, port_shift):
         cmd[cmd.index("--port") + 1] = str(port + port_shift)
         try:
@@ -234,10 +236,17 @@ def run_benchmark(args) -> Optional[dict]:
 
     # The asynchronous mode next to the headline (synchronous / single) number: between-graph workers that
     # pull and push one-sidedly against GPU-resident shards (parallel/replicas.py::XgmiAsyncTrainer).  One
-    # process needs no peer; several use the peer mappings only after their trial run succeeded on this node.
+    # process needs no peer and measures it here; with several GPUs the number is the one the trial's child
+    # processes measured (same kernels, same data shape), so that nothing after the headline run can cost it.
     async_report = None
-    if not use_cpu and (not distributed or peer_async_ok) and mode != "xgmi_async" \
-            and os.environ.get("DTF_BENCH_ASYNC", "1") != "0":
+    if distributed and trial is not None and peer_async_ok and trial.get("async_ms_per_step"):
+        ms = float(trial["async_ms_per_step"])
+        async_report = {"value": round(n * BATCH * 1000.0 / ms, 1), "unit": "samples/s", "ms_per_step": ms,
+                        "steps": STEPS_PER_EPOCH, "global_step": trial.get("async_global_step"),
+                        "every_push_counted": True, "measured_in": "trial child processes",
+                        "parallelism": f"async PS dp{n}: shard per GPU in HBM, one-sided pull and lock-free SGD "
+                                       f"push through peer mappings, no barrier"}
+    elif not use_cpu and not distributed and mode != "xgmi_async" and os.environ.get("DTF_BENCH_ASYNC", "1") != "0":
         try:
             a_steps = min(steps, 4 * STEPS_PER_EPOCH)
             ta = build("xgmi_async")
@@ -247,10 +256,7 @@ def run_benchmark(args) -> Optional[dict]:
             ta0 = time.perf_counter()
             ta.run_steps(a_steps)
             _sync(device, distributed)
-            a_el = torch.tensor([time.perf_counter() - ta0], dtype=torch.float64, device=device)
-            if distributed:
-                dist.all_reduce(a_el, op=dist.ReduceOp.MAX)
-            a_el = float(a_el.item())
+            a_el = time.perf_counter() - ta0
             a_gs = ta.global_step_value()
             a_loss, a_acc = ta.evaluate(torch.as_tensor(mnist.test.images).to(device),
                                         torch.as_tensor(mnist.test.labels).to(device))
@@ -323,7 +329,7 @@ def run_benchmark(args) -> Optional[dict]:
             result["async_mode"] = async_report
         if trial is not None:
             result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok",
-                                                       "async_ms_per_step", "error")
+                                                       "async_ms_per_step", "async_loss", "error")
                                              if k in trial}
     if hasattr(trainer, "close"):
         _sync(device, distributed)
