@@ -173,30 +173,41 @@ def run_benchmark(args) -> Optional[dict]:
         probe_ms, best = {}, None
         # (the one-GPU rehearsal keeps its gloo group out of the per-step path whenever it can)
         library = ("sync", "towers") if not share_gpu else (() if xgmi_ok else ("towers",))
-        for cand in library + (("xgmi",) if xgmi_ok else ()):
+        for cand in (("xgmi",) if xgmi_ok else ()) + library:
             if rank == 0:
                 print(f"[bench] probing {cand}", file=sys.stderr, flush=True)
-            t = build(cand)
-            prepare(t, (probe, probe))
-            t.run_steps(probe)
-            _sync(device, distributed)
-            tp = time.perf_counter()
-            t.run_steps(probe)
-            _sync(device, distributed)
-            dt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=device)
-            if distributed:
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)     # identical decision on every rank
+            try:
+                t = build(cand)
+                prepare(t, (probe, probe))
+                t.run_steps(probe)
+                _sync(device, distributed)
+                tp = time.perf_counter()
+                t.run_steps(probe)
+                _sync(device, distributed)
+                dt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=device)
+                if distributed:
+                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)     # identical decision on every rank
+            except Exception as e:  # noqa: BLE001 — a candidate that cannot run here is simply not chosen
+                print(f"[bench rank {rank}] candidate {cand} failed ({type(e).__name__}: {e})", file=sys.stderr,
+                      flush=True)
+                probe_ms[cand] = None
+                continue
             probe_ms[cand] = round(1000.0 * float(dt.item()) / probe, 5)
             if best is None or probe_ms[cand] < probe_ms[best[0]]:
+                if best is not None:
+                    retire(best[1])
                 best = (cand, t)
             else:
                 retire(t)
-                del t
+            del t
+        if best is None:
+            raise SystemExit("no data-parallel mode could run on this node")
         mode, trainer = best
         if mode != "xgmi":
             fallback_mode = None
         else:
-            fallback_mode = min((m for m in probe_ms if m != "xgmi"), key=lambda m: probe_ms[m], default=None)
+            fallback_mode = min((m for m in probe_ms if m != "xgmi" and probe_ms[m] is not None),
+                                key=lambda m: probe_ms[m], default=None)
     else:
         trainer = build(mode)
         fallback_mode = None
