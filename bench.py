@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5500)
     ap.add_argument("--warmup", type=int, default=550)
-    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "xgmi", "xgmi_async", "auto"],
+    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "xgmi", "xgmi2", "xgmi_async", "auto"],
                     help="N=1 default: single; N>1 default: auto = the faster of sync (PS shard per GPU, "
                          "reduce-scatter/all-gather) and towers (all-reduce, replicated apply), probed before warm-up")
     ap.add_argument("--chunk", type=int, default=50, help="steps captured per hipGraph replay")

@@ -128,7 +128,7 @@ def run_benchmark(args) -> Optional[dict]:
 
     def build(m):
         # gloo collectives (the one-GPU rehearsal) cannot be captured; the peer-mapped exchange can
-        graph = not args.no_graph and not (share_gpu and m not in ("xgmi", "xgmi_async"))
+        graph = not args.no_graph and not (share_gpu and m not in ("xgmi", "xgmi2", "xgmi_async"))
         extra = {"uncached_grads": bool(trial and trial.get("uncached_grads"))} if m == "xgmi" else {}
         return build_replica_trainer(mode=m, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
                                      rank=rank, world=world, chunk=int(args.chunk), use_graph=graph, **extra)
@@ -222,7 +222,7 @@ def run_benchmark(args) -> Optional[dict]:
         return time.perf_counter() - t0
 
     elapsed = timed(trainer)
-    if mode == "xgmi":
+    if mode in ("xgmi", "xgmi2"):
         # The replicas sum in rank order, so they must be bit-identical; anything else (or an exchange that
         # timed out) voids the measurement and the run is repeated with the library collectives.
         good = torch.tensor([1 if trainer.healthy() else 0, trainer.replica_checksum()], dtype=torch.int64,

@@ -119,6 +119,18 @@ int dtf_xgmi_close(void* p);
 int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
                              float* params, int64_t n, const float* lr, float* global_step, uint32_t* state,
                              int rank, int world, int timeout_ms, void* stream);
+// Two-launch step of a synchronous replica whose backward exchanges per element (mlp_step2.hip, XgParams).
+typedef struct DtfXgDesc {
+  uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox of this step's slot: 8-byte words
+                                        //   [source rank * n + element], uncached memory, zero-initialised
+  uint32_t* state;                      // 3 words in local memory: {1, 0, 0} before the first step
+  int64_t n;                            // elements per source row
+  int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
+  int32_t rank, world, timeout_ms, reserved;
+} DtfXgDesc;
+int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
+                    void* stream);
+
 // One-sided asynchronous PS traffic over the same mappings: the slab is cut into `world` shards of `chunk`
 // floats, shard k authoritative in rank k's buffer (shards[k], slab-sized).  See xgmi.hip.
 int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local, void* stream);

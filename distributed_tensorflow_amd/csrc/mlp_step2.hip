@@ -535,8 +535,62 @@ constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * 64 > 2 * 128 * kLdw
 constexpr int bwd16_smem_floats(int NA) { return bwd16_red_floats(NA) + 128 * kLdz + 32 * kLdw + 256 + 64; }
 
 // (bx, by) = position in the backward part of the grid, `lin` = linear id for the profiling stamps.
-template <int NS, int CQ, int NA, bool YV2>
-__device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin) {
+// ---- cross-replica variant of the fused backward (synchronous data parallelism over peer-mapped HBM) ----
+// Every THREAD exchanges its own output element with the same thread of the other replicas before it applies
+// it.  Values travel as 8-byte words {exchange number, value}: the thread stores its (1/N-scaled) partial into
+// its row of every peer's inbox with one write-through store per peer, then polls its own inbox -- local,
+// uncached memory the peers write into -- until the word of every peer carries this exchange's number, adds
+// the values in rank order (bit-identical on every replica) and performs the in-place SGD update of the fused
+// mode.  An 8-byte aligned store arrives whole, so the number doubles as the arrival flag: no separate flag,
+// no wait for a write acknowledgement, no barrier of any kind; the added latency is one xGMI write.
+// Two inbox slots alternate with the step parity: a replica that has finished step s has received every peer's
+// step-s values, hence every peer's step s-1 launch -- the last reader of the slot step s+1 overwrites -- is over.
+struct XgParams {
+  uint64_t* inbox[DTF_XGMI_MAX_RANKS];    // this slot's inbox of every rank: word [source * n + element]
+  uint32_t* state;                        // [0] exchange number, [1] finished workgroups, [2] error
+  long n;                                 // elements per source row
+  long offW1, offb1, offW2, offb2;        // element offsets of the four gradients inside a row
+  int rank, world, nblocks;
+  long long timeout_ticks;
+};
+
+// Publishes `own` as element e of exchange `seq` and returns the rank-ordered sum over all replicas.
+// *failed is raised (and the caller must not apply the result) when a peer's value never arrives.
+__device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, long e, float own, int* failed) {
+  const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
+#pragma unroll
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r)
+    if (r < x.world && r != x.rank)
+      __hip_atomic_store(x.inbox[r] + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint64_t* mine = x.inbox[x.rank] + e;
+  uint64_t v[DTF_XGMI_MAX_RANKS];
+  const long long t0 = wall_clock64();
+  for (unsigned spin = 1;; ++spin) {
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+      if (r < x.world && r != x.rank) {
+        v[r] = __hip_atomic_load(mine + (long)r * x.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = all && (unsigned)(v[r] >> 32) == seq;
+      }
+    }
+    if (all) break;
+    if ((spin & 63u) == 0u && wall_clock64() - t0 > x.timeout_ticks) {
+      *failed = 1;
+      return own;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r)
+    if (r < x.world) total += (r == x.rank) ? own : __uint_as_float((unsigned)v[r]);
+  return total;
+}
+
+template <int NS, int CQ, int NA, bool YV2, bool XG = false>
+__device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin,
+                                                const XgParams* xg = nullptr) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
   constexpr int kTileRows = 16 * NA;
   float* red = smem;                         // [8 waves][4 NA][64] partial tiles (phase 2+)
@@ -618,6 +672,13 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   // the step counter travels with the other old values instead of a dependent load + store at the
   // very end of the statistics block (which finishes last); any valid address when there is none
   const float gs_old = *(p.global_step ? p.global_step : p.lr);
+  unsigned xg_seq = 0u;
+  __shared__ int xg_failed;
+  if constexpr (XG) {
+    xg_seq = __hip_atomic_load(&xg->state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned poisoned = __hip_atomic_load(&xg->state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) xg_failed = poisoned ? 1 : 0;       // published by the barrier that ends phase 1
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   DTF_STAMP2_AT(lin, 1);
@@ -686,6 +747,52 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
       for (int g = 0; g < 4; ++g) red[(wave * 4 * NA + 4 * sa + g) * 64 + lane] = acc[sa][g];
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
+    if constexpr (XG) {
+      const XgParams& x = *xg;
+      const bool live = xg_failed == 0;       // an earlier exchange failed: nothing is sent, nothing applied
+      int lost = 0;
+#pragma unroll
+      for (int u = 0; u < kOuts; ++u) {
+        const int o = tid + u * kBwdThreads;
+        if (o < 256 * NA) {
+          const int o_sub = o >> 8, o_reg = (o >> 6) & 3, o_ln = o & 63;
+          const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * 64 + o_ln];
+          if (is_main) {
+            const int orow = k0 + o_trow, ocol = h0 + o_tcol;
+            if (orow < K && ocol < H && live) {
+              const long e = (long)orow * H + ocol;
+              const float total = xg_exchange(x, xg_seq, x.offW1 + e, gs * s, &lost);
+              if (!lost) p.oW1[e] = wold[u] - lr * total;
+            }
+          } else if (o_sub == 0) {
+            const int h = h0 + o_trow;
+            if (h < H && o_tcol < C && live) {
+              const long e = (long)h * C + o_tcol;
+              const float total = xg_exchange(x, xg_seq, x.offW2 + e, gs * s, &lost);
+              if (!lost) p.oW2[e] = w2t[o_trow * kLdw + o_tcol] - lr * total;
+            }
+          }
+        }
+      }
+      if (is_main && tk == 0) {
+        __syncthreads();   // red is reused
+        db1part += __shfl_xor(db1part, 16);
+        db1part += __shfl_xor(db1part, 32);
+        if (lane < 16) red[wave * 16 + lane] = db1part;
+        __syncthreads();
+        if (tid < 16 && h0 + tid < H && live) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
+          const float total = xg_exchange(x, xg_seq, x.offb1 + h0 + tid, gs * s, &lost);
+          if (!lost) p.ob1[h0 + tid] = b1old - lr * total;
+        }
+      }
+      if (lost) xg_failed = 1;
+    } else {
 #pragma unroll
     for (int u = 0; u < kOuts; ++u) {
       const int o = tid + u * kBwdThreads;
@@ -719,6 +826,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         p.ob1[h0 + tid] = p.fused ? b1old - lr * s : gs * s;
       }
     }
+    }   // !XG
     DTF_STAMP2_AT(lin, 6);
   } else {
     DTF_STAMP2_AT(lin, 3);
@@ -748,7 +856,18 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     }
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
-    if (tid < C) {
+    if constexpr (XG) {
+      const XgParams& x = *xg;
+      if (tid < C && xg_failed == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
+        int lost = 0;
+        const float total = xg_exchange(x, xg_seq, x.offb2 + tid, gs * s, &lost);
+        if (!lost) p.ob2[tid] = b2s[tid] - lr * total;
+        else xg_failed = 1;
+      }
+    } else if (tid < C) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
@@ -764,6 +883,18 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
       DTF_STAMP2_AT(lin, 6);
     }
   }
+  if constexpr (XG) {
+    // the last workgroup out advances the exchange number for the next launch on this stream
+    __syncthreads();
+    if (tid == 0) {
+      if (xg_failed) atomicExch(&xg->state[2], 1u);
+      const unsigned done = __hip_atomic_fetch_add(&xg->state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (unsigned)xg->nblocks - 1u) {
+        __hip_atomic_store(&xg->state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&xg->state[0], xg_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   DTF_STAMP2_AT(lin, 7);
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
@@ -772,6 +903,12 @@ template <int NS, int CQ, bool YV2>
 __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
   bwd_tile16_body<NS, CQ, 2, YV2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+template <int NS, int CQ, bool YV2>
+__global__ __launch_bounds__(kBwdThreads) void bwd_tile16_xg_kernel(BwdParams p, XgParams x) {
+  __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
+  bwd_tile16_body<NS, CQ, 2, YV2, true>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1063,8 +1200,8 @@ bool dtf_step2_supported(int B, int K, int H, int C) {
 // parity selects the half of the logit ping-pong workspace this step accumulates
 // into; consecutive steps MUST alternate it (the other half is cleared for the
 // next step by the forward launch).
-int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
-                     hipStream_t stream) {
+static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
+                             hipStream_t stream, XgParams* xg) {
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
   if (!dtf_step2_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
   const bool fused = mode == DTF_HEAD_FUSED;
@@ -1132,12 +1269,54 @@ int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode
   const dim3 grid(tiles_h, tiles_k + 2), block(kBwdThreads);
   // labels as 8-byte loads when every row pair is 8-byte aligned
   const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
-  if (cq <= 3 && yv2) {
+  if (xg) {
+    xg->nblocks = tiles_h * (tiles_k + 1) + 1;      // every workgroup that does not return at once
+    if (cq <= 3 && yv2) {
+      hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true>), grid, block, 0, stream, p, *xg);
+    } else {
+      hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false>), grid, block, 0, stream, p, *xg);
+    }
+  } else if (cq <= 3 && yv2) {
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
   } else {
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 4, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
+                     hipStream_t stream) {
+  return launch_step2_impl(d, batch_index, parity, mode, grad_scale, stream, nullptr);
+}
+
+// Fused step of a synchronous replica: forward, then a backward whose threads exchange their partial
+// gradients (scaled by grad_scale = 1/N) with the same threads of the peers through the inboxes in x and
+// apply the rank-ordered sum in place.  Two launches; see XgParams.
+extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
+                               void* stream) {
+  if (!d || !x) return DTF_ERR_NULL;
+  if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
+  if (x->world < 1 || x->world > DTF_XGMI_MAX_RANKS || x->rank < 0 || x->rank >= x->world) return DTF_ERR_SHAPE;
+  if (!x->state) return DTF_ERR_NULL;
+  {
+    const long K = d->in_dim, H = d->hidden, C = d->classes;
+    if (x->offW1 < 0 || x->offW1 + K * H > x->n || x->offb1 < 0 || x->offb1 + H > x->n || x->offW2 < 0 ||
+        x->offW2 + H * C > x->n || x->offb2 < 0 || x->offb2 + C > x->n)
+      return DTF_ERR_SHAPE;
+  }
+  XgParams a;
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+    a.inbox[r] = r < x->world ? reinterpret_cast<uint64_t*>(x->inbox[r]) : nullptr;
+    if (r < x->world && (!a.inbox[r] || (x->inbox[r] & 7u))) return DTF_ERR_NULL;
+  }
+  a.state = x->state;
+  a.n = x->n;
+  a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
+  a.rank = x->rank;
+  a.world = x->world;
+  a.nblocks = 0;
+  a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a);
 }
 
 // Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.

@@ -274,6 +274,14 @@ class MLPEngine:
             finally:
                 self.g = keep
 
+    def step_xg(self, batch_index: Optional[int], scale: float, xg: "hb.DtfXgDesc"):
+        """Fused step of a synchronous replica: the backward's workgroups exchange their partial gradients
+        (scaled by ``scale`` = 1/N) with the peers described by ``xg`` and apply the rank-ordered sum in place."""
+        if not self.on_gpu:
+            raise RuntimeError("the cross-replica step is a GPU path")
+        hb.mlp_step_xg(self._descriptor(), self._bi(batch_index), self.parity, scale, xg)
+        self.parity ^= 1
+
     def advance(self, n: int = 1):
         self._host_cursor += n
 

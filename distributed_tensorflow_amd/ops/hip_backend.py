@@ -74,6 +74,24 @@ class DtfPipeDesc(C.Structure):
     ]
 
 
+class DtfXgDesc(C.Structure):
+    """Mirror of ``struct DtfXgDesc`` (the replicas' inboxes of the cross-replica two-launch step)."""
+
+    _fields_ = [
+        ("inbox", C.c_uint64 * 16),
+        ("state", C.c_void_p),
+        ("n", C.c_int64),
+        ("offW1", C.c_int64),
+        ("offb1", C.c_int64),
+        ("offW2", C.c_int64),
+        ("offb2", C.c_int64),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("timeout_ms", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 def _declare(lib: C.CDLL) -> None:
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     lib.dtf_mlp_chunk_pipelined.argtypes = [C.POINTER(DtfMlpDesc), C.POINTER(DtfPipeDesc), i32, i32, vp]
@@ -96,6 +114,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.dtf_xgmi_close.argtypes = [vp]
     lib.dtf_xgmi_allreduce_apply.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
+    lib.dtf_mlp_step_xg.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, C.POINTER(DtfXgDesc), vp]
+    lib.dtf_mlp_step_xg.restype = C.c_int
     lib.dtf_enable_peer_access.argtypes = [i32, i32]
     lib.dtf_enable_peer_access.restype = C.c_int
     lib.dtf_xgmi_pull.argtypes = [vp, i32, i64, vp, vp]
@@ -292,6 +312,11 @@ def mlp_chunk_pipelined_supported(B: int, K: int, H: int, Cn: int) -> bool:
 def mlp_step_grad(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float = 1.0):
     _check(require().dtf_mlp_step_grad(C.byref(desc), int(batch_index), int(parity), float(grad_scale),
                                        _stream()), "dtf_mlp_step_grad")
+
+
+def mlp_step_xg(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float, xg: DtfXgDesc):
+    _check(require().dtf_mlp_step_xg(C.byref(desc), int(batch_index), int(parity), float(grad_scale), C.byref(xg),
+                                     _stream()), "dtf_mlp_step_xg")
 
 
 def advance_cursor(cursor: torch.Tensor, n: int):

@@ -396,6 +396,49 @@ class XgmiTowerTrainer(_BaseTrainer):
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
 
+class XgmiFusedTrainer(_BaseTrainer):
+    """Synchronous replicas whose gradient exchange happens INSIDE the backward launch: 2 launches per step.
+
+    Same update as ``XgmiTowerTrainer`` (the mean of N gradients applied once to every replica, sums in rank
+    order, replicas bit-identical).  Every backward thread stores its own element of the 1/N-scaled gradient as
+    an 8-byte {exchange number, value} word straight into every peer's inbox, polls its own inbox for the
+    peers' words and applies the in-place SGD update (``csrc/mlp_step2.hip``, ``bwd_tile16_xg_kernel``;
+    ``parallel/xgmi.py::PeerInbox``).  No flag array, no barrier, no separate exchange kernel: the exchange adds
+    one xGMI write latency to the backward.
+    """
+
+    name = "xgmi2"
+
+    def __init__(self, *a, group=None, timeout_ms: int = 20000, **kw):
+        kw["need_grads"] = False
+        super().__init__(*a, **kw)
+        if self.device.type != "cuda":
+            raise RuntimeError("the peer-mapped exchange is a GPU path")
+        from .xgmi import PeerInbox
+
+        self.engine.global_step = self.global_step
+        self.engine._desc = None
+        self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
+                            timeout_ms=timeout_ms)
+        offs = {role: self.layout.var_range[name][0] for role, name in
+                (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
+                 ("b2", "biases/Variable_1"))}
+        self._xg_desc = [self.xg.step_descriptor(s, offs) for s in (0, 1)]
+
+    def _one_step(self, batch_index: int):
+        self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc[self.engine.parity])
+
+    _capture = XgmiTowerTrainer._capture
+    replica_checksum = XgmiTowerTrainer.replica_checksum
+    healthy = XgmiTowerTrainer.healthy
+    close = XgmiTowerTrainer.close
+
+    def describe(self):
+        return (f"sync towers dp{self.world}: gradient exchange inside the backward launch ({{number, value}} words "
+                f"stored into the peers' inboxes over peer-mapped HBM, rank-ordered sum, in-place SGD), "
+                f"2 launches/step" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
+
+
 class XgmiAsyncTrainer(_BaseTrainer):
     """Between-graph ASYNCHRONOUS workers on N GPUs with GPU-resident PS shards reached one-sidedly.
 
@@ -473,7 +516,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi_async": XgmiAsyncTrainer}[mode]
+           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi_async": XgmiAsyncTrainer}[mode]
     if mode == "single" and kw.get("world", 1) != 1:
         raise ValueError("single mode is one process")
     return cls(**kw)

@@ -270,3 +270,84 @@ class PeerShards:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+
+class PeerInbox:
+    """Inboxes of the exchange that runs INSIDE the backward launch (``hb.mlp_step_xg``).
+
+    Every replica owns, in uncached memory, two slots (even / odd steps) of ``world`` rows of ``numel`` 8-byte
+    words.  Row *s* of a replica's inbox is written by replica *s* only: one word {exchange number, value} per
+    gradient element, stored straight into the peer's HBM; the owner polls its own inbox.  The number in the
+    upper half of a word is the arrival flag of its lower half.
+    """
+
+    def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None, timeout_ms: int = 5000):
+        lib = hb.require()
+        if not 1 <= world <= lib.dtf_xgmi_max_ranks():
+            raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        self.numel = int(numel)
+        self.timeout_ms = int(timeout_ms)
+        self.slot_bytes = self.world * self.numel * 8
+        self._closed = False
+        self._mapped: List[int] = []
+        with torch.cuda.device(self.device):
+            self._ptr = _alloc(2 * self.slot_bytes, True)
+            self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.state[0] = 1                          # exchanges are numbered from 1; an empty inbox holds 0
+        self._ptrs = [0] * self.world
+        self._ptrs[self.rank] = self._ptr
+        if self.world > 1:
+            import torch.distributed as dist
+
+            everyone: List[Optional[dict]] = [None] * self.world
+            dist.all_gather_object(everyone, {"rank": self.rank, "handle": _export(self._ptr),
+                                              "bytes": self.slot_bytes}, group=group)
+            with torch.cuda.device(self.device):
+                for h in everyone:
+                    if h["rank"] == self.rank:
+                        continue
+                    if h["bytes"] != self.slot_bytes:
+                        raise RuntimeError("replicas disagree on the inbox size")
+                    self._ptrs[h["rank"]] = _open(h["handle"])
+                    self._mapped.append(self._ptrs[h["rank"]])
+            dist.barrier(group=group)                  # nobody writes into an inbox that is not mapped yet
+
+    def step_descriptor(self, slot: int, offsets: dict) -> "hb.DtfXgDesc":
+        """Arguments of ``hb.mlp_step_xg`` for steps of parity ``slot``; ``offsets`` maps W1 / b1 / W2 / b2 to
+        the element offsets of their gradients inside a row."""
+        d = hb.DtfXgDesc()
+        for r in range(self.world):
+            d.inbox[r] = self._ptrs[r] + (self.slot_bytes if slot & 1 else 0)
+        d.state = self.state.data_ptr()
+        d.n = self.numel
+        d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
+        d.rank, d.world, d.timeout_ms = self.rank, self.world, self.timeout_ms
+        return d
+
+    def failed(self) -> bool:
+        return bool(int(self.state[2].item()))
+
+    def exchanges_done(self) -> int:
+        return int(self.state[0].item()) - 1
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        lib = hb.require()
+        try:
+            torch.cuda.synchronize(self.device)
+        except Exception:  # noqa: BLE001 — tearing down after a device error
+            pass
+        with torch.cuda.device(self.device):
+            for p in self._mapped:
+                lib.dtf_xgmi_close(p)
+            lib.dtf_xgmi_free(self._ptr)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

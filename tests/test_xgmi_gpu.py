@@ -68,3 +68,20 @@ def test_async_workers_update_shared_shards_one_sidedly(world, use_graph):
         assert r["global_step"] == world * steps, r           # every push counted, atomically
         assert r["moved"] > 1e-3 and r["loss_after"] < r["loss_before"], r
         assert "one-sided" in r["describe"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,use_graph", [(1, True), (2, False), (2, True), (3, True)])
+def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_graph):
+    """Two launches per step: every backward thread swaps its element with the same thread of the peers.
+    (More than three replica processes do not fit on ONE GPU together: their spinning workgroups would wait for
+    workgroups of a peer that cannot become resident.  One process per GPU has no such limit.)"""
+    steps = 7
+    for r in _run_replicas(world, steps, use_graph, uncached=1, mode="sync2"):
+        assert r["healthy"], r
+        assert r["identical"] and r["same_sum"], r
+        assert r["global_step"] == steps
+        assert r["moved"] > 1e-3
+        assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r
+        assert "inside the backward launch" in r["describe"]
