@@ -123,7 +123,7 @@ int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, 
 typedef struct DtfXgDesc {
   uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox of this step's slot: 8-byte words
                                         //   [source rank * n + element], uncached memory, zero-initialised
-  uint32_t* state;                      // 3 words in local memory: {1, 0, 0} before the first step
+  uint32_t* state;                      // 4 zero-initialised words in local memory
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
   int32_t rank, world, timeout_ms, reserved;

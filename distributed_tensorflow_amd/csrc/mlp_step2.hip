@@ -248,11 +248,15 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
     const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
     const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
     float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
-    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs) {
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs,
+    unsigned* __restrict__ exchange_counter) {
   // The last grid row holds no tile: its first workgroup refreshes the shadow copy of W2/b2 and
   // clears the other logit accumulator, beside the tiles instead of at the tail of one of them.
+  // For the cross-replica backward of the SAME step it also numbers the exchange: one writer, in a launch
+  // of its own, so every workgroup of the backward launch reads the same number without any atomic.
   if (blockIdx.y == gridDim.y - 1) {
     if (blockIdx.x == 0) {
+      if (exchange_counter && threadIdx.x == 0) *exchange_counter += 1u;
       const int hcw = H * C;
       if (shadow_dst)
         for (int e = threadIdx.x; e < hcw + C; e += kFwdWaves * 64) shadow_dst[e] = e < hcw ? W2[e] : b2[e - hcw];
@@ -547,51 +551,59 @@ constexpr int bwd16_smem_floats(int NA) { return bwd16_red_floats(NA) + 128 * kL
 // step-s values, hence every peer's step s-1 launch -- the last reader of the slot step s+1 overwrites -- is over.
 struct XgParams {
   uint64_t* inbox[DTF_XGMI_MAX_RANKS];    // this slot's inbox of every rank: word [source * n + element]
-  uint32_t* state;                        // [0] exchange number, [1] finished workgroups, [2] error
+  uint32_t* state;                        // [0] exchange number (bumped by the forward launch), [2] error
   long n;                                 // elements per source row
   long offW1, offb1, offW2, offb2;        // element offsets of the four gradients inside a row
-  int rank, world, nblocks;
+  int rank, world;
   long long timeout_ticks;
 };
 
 // Publishes `own` as element e of exchange `seq` and returns the rank-ordered sum over all replicas.
+// W: compile-time bound on the replica count (keeps the code small and every peer's load in flight at once).
 // *failed is raised (and the caller must not apply the result) when a peer's value never arrives.
+template <int W>
 __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, long e, float own, int* failed) {
   const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
 #pragma unroll
-  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r)
+  for (int r = 0; r < W; ++r)
     if (r < x.world && r != x.rank)
       __hip_atomic_store(x.inbox[r] + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint64_t* mine = x.inbox[x.rank] + e;
-  uint64_t v[DTF_XGMI_MAX_RANKS];
-  const long long t0 = wall_clock64();
+  uint64_t v[W];
+  long long t0 = 0;
+#pragma unroll 1
   for (unsigned spin = 1;; ++spin) {
     bool all = true;
 #pragma unroll
-    for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+    for (int r = 0; r < W; ++r) {
       if (r < x.world && r != x.rank) {
         v[r] = __hip_atomic_load(mine + (long)r * x.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         all = all && (unsigned)(v[r] >> 32) == seq;
       }
     }
     if (all) break;
-    if ((spin & 63u) == 0u && wall_clock64() - t0 > x.timeout_ticks) {
-      *failed = 1;
-      return own;
+    if ((spin & 63u) == 0u) {               // the clock is read only once the wait is long
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > x.timeout_ticks) {
+        *failed = 1;
+        return own;
+      }
     }
     __builtin_amdgcn_s_sleep(1);
   }
   float total = 0.f;
 #pragma unroll
-  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r)
+  for (int r = 0; r < W; ++r)
     if (r < x.world) total += (r == x.rank) ? own : __uint_as_float((unsigned)v[r]);
   return total;
 }
 
-template <int NS, int CQ, int NA, bool YV2, bool XG = false>
+template <int NS, int CQ, int NA, bool YV2, int XW = 0>
 __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin,
                                                 const XgParams* xg = nullptr) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
+  constexpr bool XG = XW > 0;             // cross-replica variant for up to XW replicas
   constexpr int kTileRows = 16 * NA;
   float* red = smem;                         // [8 waves][4 NA][64] partial tiles (phase 2+)
   float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
@@ -672,12 +684,12 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   // the step counter travels with the other old values instead of a dependent load + store at the
   // very end of the statistics block (which finishes last); any valid address when there is none
   const float gs_old = *(p.global_step ? p.global_step : p.lr);
-  unsigned xg_seq = 0u;
-  __shared__ int xg_failed;
+  unsigned xg_seq = 0u, xg_poisoned = 0u;
   if constexpr (XG) {
-    xg_seq = __hip_atomic_load(&xg->state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned poisoned = __hip_atomic_load(&xg->state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) xg_failed = poisoned ? 1 : 0;       // published by the barrier that ends phase 1
+    // number of this exchange: bumped by the forward launch of the same step (one writer, earlier launch);
+    // both words are consumed at the exchange only, so their latency hides behind everything in between
+    xg_seq = xg->state[0];
+    xg_poisoned = xg->state[2];
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -702,6 +714,12 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   __syncthreads();
   DTF_STAMP2_AT(lin, 2);
   const float gs = p.grad_scale;
+  // cross-replica variant: what this thread swaps with its peers (slot 0: its tile / bias element, slot 1: a b1
+  // element of the k-tile-0 workgroups), gathered first and exchanged at ONE place further down
+  bool xv[2] = {false, false};
+  long xe[2] = {0, 0};
+  float xown[2] = {0.f, 0.f}, xold[2] = {0.f, 0.f};
+  float* xdst[2] = {nullptr, nullptr};
 
   if (!stats_block) {
     // ---- phase 2: rows beyond the batch need no mask (their dz3 rows are zero) ----------------
@@ -748,33 +766,29 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
     if constexpr (XG) {
-      const XgParams& x = *xg;
-      const bool live = xg_failed == 0;       // an earlier exchange failed: nothing is sent, nothing applied
-      int lost = 0;
+      static_assert(kOuts == 1, "one tile element per thread");
+      {
+        const int o = tid;
+        const int o_sub = o >> 8, o_reg = (o >> 6) & 3, o_ln = o & 63;
+        const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
+        float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < kOuts; ++u) {
-        const int o = tid + u * kBwdThreads;
-        if (o < 256 * NA) {
-          const int o_sub = o >> 8, o_reg = (o >> 6) & 3, o_ln = o & 63;
-          const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
-          float s = 0.f;
-#pragma unroll
-          for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * 64 + o_ln];
-          if (is_main) {
-            const int orow = k0 + o_trow, ocol = h0 + o_tcol;
-            if (orow < K && ocol < H && live) {
-              const long e = (long)orow * H + ocol;
-              const float total = xg_exchange(x, xg_seq, x.offW1 + e, gs * s, &lost);
-              if (!lost) p.oW1[e] = wold[u] - lr * total;
-            }
-          } else if (o_sub == 0) {
-            const int h = h0 + o_trow;
-            if (h < H && o_tcol < C && live) {
-              const long e = (long)h * C + o_tcol;
-              const float total = xg_exchange(x, xg_seq, x.offW2 + e, gs * s, &lost);
-              if (!lost) p.oW2[e] = w2t[o_trow * kLdw + o_tcol] - lr * total;
-            }
-          }
+        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * 64 + o_ln];
+        xown[0] = gs * s;
+        if (is_main) {
+          const int orow = k0 + o_trow, ocol = h0 + o_tcol;
+          const long e = (long)orow * H + ocol;
+          xv[0] = o < 256 * NA && orow < K && ocol < H;
+          xe[0] = xg->offW1 + e;
+          xold[0] = wold[0];
+          xdst[0] = p.oW1 + e;
+        } else {
+          const int h = h0 + o_trow;
+          const long e = (long)h * C + o_tcol;
+          xv[0] = o < 256 * NA && o_sub == 0 && h < H && o_tcol < C;
+          xe[0] = xg->offW2 + e;
+          xold[0] = w2t[(o_trow & 15) * kLdw + o_tcol];
+          xdst[0] = p.oW2 + e;
         }
       }
       if (is_main && tk == 0) {
@@ -783,15 +797,17 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         db1part += __shfl_xor(db1part, 32);
         if (lane < 16) red[wave * 16 + lane] = db1part;
         __syncthreads();
-        if (tid < 16 && h0 + tid < H && live) {
+        if (tid < 16 && h0 + tid < H) {
           float s = 0.f;
 #pragma unroll
           for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
-          const float total = xg_exchange(x, xg_seq, x.offb1 + h0 + tid, gs * s, &lost);
-          if (!lost) p.ob1[h0 + tid] = b1old - lr * total;
+          xv[1] = true;
+          xe[1] = xg->offb1 + h0 + tid;
+          xown[1] = gs * s;
+          xold[1] = b1old;
+          xdst[1] = p.ob1 + h0 + tid;
         }
       }
-      if (lost) xg_failed = 1;
     } else {
 #pragma unroll
     for (int u = 0; u < kOuts; ++u) {
@@ -857,15 +873,15 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
     if constexpr (XG) {
-      const XgParams& x = *xg;
-      if (tid < C && xg_failed == 0) {
+      if (tid < C) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kBwdWaves; ++w) s += red[w * 16 + tid];
-        int lost = 0;
-        const float total = xg_exchange(x, xg_seq, x.offb2 + tid, gs * s, &lost);
-        if (!lost) p.ob2[tid] = b2s[tid] - lr * total;
-        else xg_failed = 1;
+        xv[0] = true;
+        xe[0] = xg->offb2 + tid;
+        xown[0] = gs * s;
+        xold[0] = b2s[tid];
+        xdst[0] = p.ob2 + tid;
       }
     } else if (tid < C) {
       float s = 0.f;
@@ -884,15 +900,17 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     }
   }
   if constexpr (XG) {
-    // the last workgroup out advances the exchange number for the next launch on this stream
-    __syncthreads();
-    if (tid == 0) {
-      if (xg_failed) atomicExch(&xg->state[2], 1u);
-      const unsigned done = __hip_atomic_fetch_add(&xg->state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done == (unsigned)xg->nblocks - 1u) {
-        __hip_atomic_store(&xg->state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&xg->state[0], xg_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const XgParams& x = *xg;
+    const unsigned seq = xg_seq;
+    if (xg_poisoned == 0u) {                 // after a failed exchange nothing is sent and nothing applied
+      int lost = 0;
+#pragma unroll 1
+      for (int item = 0; item < 2; ++item) {
+        if (!xv[item]) continue;
+        const float total = xg_exchange<XW>(x, seq, xe[item], xown[item], &lost);
+        if (!lost) *xdst[item] = xold[item] - lr * total;
       }
+      if (lost) atomicExch(&x.state[2], 1u);
     }
   }
   DTF_STAMP2_AT(lin, 7);
@@ -905,10 +923,10 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   bwd_tile16_body<NS, CQ, 2, YV2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-template <int NS, int CQ, bool YV2>
+template <int NS, int CQ, bool YV2, int XW>
 __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_xg_kernel(BwdParams p, XgParams x) {
   __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
-  bwd_tile16_body<NS, CQ, 2, YV2, true>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
+  bwd_tile16_body<NS, CQ, 2, YV2, XW>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1219,7 +1237,9 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
   const bool tile8 = g_fwd_tile8 && (K & 3) == 0 && K >= 16 && ns8 <= 4;
 #define DTF_FWD8_ARGS                                                                                 \
   dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
-      zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
+      zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}, \
+      (xg ? xg->state : (unsigned*)nullptr)
+  if (xg && !tile8) return DTF_ERR_UNSUPPORTED;      // the exchange is numbered by the 8x8 forward's duty workgroup
   if (tile8 && ns8 == 2) {
     hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_FWD8_ARGS);
   } else if (tile8 && ns8 == 1) {
@@ -1270,12 +1290,17 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
   // labels as 8-byte loads when every row pair is 8-byte aligned
   const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
   if (xg) {
-    xg->nblocks = tiles_h * (tiles_k + 1) + 1;      // every workgroup that does not return at once
-    if (cq <= 3 && yv2) {
-      hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true>), grid, block, 0, stream, p, *xg);
-    } else {
-      hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false>), grid, block, 0, stream, p, *xg);
-    }
+    const bool fast = cq <= 3 && yv2;
+#define DTF_XG_LAUNCH(W)                                                                            \
+  do {                                                                                              \
+    if (fast) hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true, W>), grid, block, 0, stream, p, *xg);  \
+    else hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false, W>), grid, block, 0, stream, p, *xg);      \
+  } while (0)
+    if (xg->world <= 2) DTF_XG_LAUNCH(2);
+    else if (xg->world <= 4) DTF_XG_LAUNCH(4);
+    else if (xg->world <= 8) DTF_XG_LAUNCH(8);
+    else DTF_XG_LAUNCH(16);
+#undef DTF_XG_LAUNCH
   } else if (cq <= 3 && yv2) {
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
   } else {
@@ -1314,7 +1339,6 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
   a.rank = x->rank;
   a.world = x->world;
-  a.nblocks = 0;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock
   return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a);
 }
@@ -1387,7 +1411,7 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     const int ns8 = ((K + 15) / 16 + 31) / 32;
     const dim3 grid(tiles_n8, tiles_m8 + 1), block(kFwdWaves * 64);
 #define DTF_F0_ARGS grid, block, 0, stream, d->x, (long)first_batch, d->W1, d->b1, d->W2, a2buf[0], zw[0], zw[1], \
-                    R * 16, B, K, H, C, d->act, (float*)nullptr, d->b2, BlockStamps{nullptr}
+                    R * 16, B, K, H, C, d->act, (float*)nullptr, d->b2, BlockStamps{nullptr}, (unsigned*)nullptr
     if (ns8 == 1) {
       hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_F0_ARGS);
     } else {

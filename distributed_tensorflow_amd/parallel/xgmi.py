@@ -294,8 +294,9 @@ class PeerInbox:
         self._mapped: List[int] = []
         with torch.cuda.device(self.device):
             self._ptr = _alloc(2 * self.slot_bytes, True)
+            # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and an
+            # empty inbox, all zeros, never matches), [2]: error
             self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
-            self.state[0] = 1                          # exchanges are numbered from 1; an empty inbox holds 0
         self._ptrs = [0] * self.world
         self._ptrs[self.rank] = self._ptr
         if self.world > 1:
@@ -330,7 +331,7 @@ class PeerInbox:
         return bool(int(self.state[2].item()))
 
     def exchanges_done(self) -> int:
-        return int(self.state[0].item()) - 1
+        return int(self.state[0].item())
 
     def close(self):
         if self._closed:
