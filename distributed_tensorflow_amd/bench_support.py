@@ -58,16 +58,18 @@ def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int) -> dict:
     def attempt(extra, port_shift):
         cmd[cmd.index("--port") + 1] = str(port + port_shift)
         try:
-            r = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=150)
-        except subprocess.TimeoutExpired:
-            return {"ok": False, "error": "trial timed out"}
-        for line in reversed(r.stdout.splitlines()):
+            r = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=180)
+            text, note = r.stdout, f"trial exited {r.returncode}"
+        except subprocess.TimeoutExpired as e:      # the stages that finished have already reported
+            text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+            note = "trial timed out"
+        for line in reversed(text.splitlines()):
             if line.startswith("{"):
                 try:
                     return json.loads(line)
                 except ValueError:
                     break
-        return {"ok": False, "error": f"trial exited {r.returncode}: {r.stdout[-300:]}"}
+        return {"ok": False, "error": f"{note}: {text[-300:]}"}
 
     res = attempt([], 0)
     res["uncached_grads"] = False
@@ -111,12 +113,12 @@ def run_benchmark(args) -> Optional[dict]:
     if distributed:
         lib_backend = not (use_cpu or share_gpu)
         dist.init_process_group(backend="nccl" if lib_backend else "gloo", device_id=device if lib_backend else None)
-    xgmi_ok = peer_async_ok = False
+    xgmi_ok = xgmi2_ok = peer_async_ok = False
     if trial is not None:
-        flag = torch.tensor([1 if trial.get("ok") else 0, 1 if trial.get("async_ok") else 0], dtype=torch.int32,
+        flag = torch.tensor([1 if trial.get(k) else 0 for k in ("ok", "async_ok", "ok2")], dtype=torch.int32,
                             device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        xgmi_ok, peer_async_ok = bool(int(flag[0].item())), bool(int(flag[1].item()))
+        xgmi_ok, peer_async_ok, xgmi2_ok = (bool(int(v)) for v in flag.tolist())
         if rank == 0 and not xgmi_ok:
             print(f"[bench] peer-mapped exchange not used on this node: {trial}", flush=True)
 
@@ -161,10 +163,11 @@ def run_benchmark(args) -> Optional[dict]:
             _sync(device, distributed)
             tr.close()
 
-    # Three synchronous data-parallel exchanges compute the same update (the mean gradient applied once):
+    # Four synchronous data-parallel exchanges compute the same update (the mean gradient applied once):
     # PS shard per GPU (reduce-scatter -> sharded SGD -> all-gather) and replicated apply after one
-    # all-reduce, both over RCCL, and the one-kernel exchange over peer-mapped HBM (parallel/xgmi.py; offered
-    # only after its trial run in a child process succeeded on this node).  Which one is faster for a 318 KB
+    # all-reduce, both over RCCL, and two exchanges over peer-mapped HBM -- one kernel after the backward, or
+    # inside the backward launch (parallel/xgmi.py; offered only after their trial run in child processes
+    # succeeded on this node).  Which one is faster for a 318 KB
     # message is a property of the RCCL build and the xGMI topology, so "auto" times a short probe of each
     # (untimed, before the warm-up) and keeps the winner.
     probe_ms = None
@@ -173,7 +176,7 @@ def run_benchmark(args) -> Optional[dict]:
         probe_ms, best = {}, None
         # (the one-GPU rehearsal keeps its gloo group out of the per-step path whenever it can)
         library = ("sync", "towers") if not share_gpu else (() if xgmi_ok else ("towers",))
-        for cand in (("xgmi",) if xgmi_ok else ()) + library:
+        for cand in (("xgmi2",) if xgmi2_ok else ()) + (("xgmi",) if xgmi_ok else ()) + library:
             if rank == 0:
                 print(f"[bench] probing {cand}", file=sys.stderr, flush=True)
             try:
@@ -203,10 +206,10 @@ def run_benchmark(args) -> Optional[dict]:
         if best is None:
             raise SystemExit("no data-parallel mode could run on this node")
         mode, trainer = best
-        if mode != "xgmi":
+        if mode not in ("xgmi", "xgmi2"):
             fallback_mode = None
-        else:
-            fallback_mode = min((m for m in probe_ms if m != "xgmi" and probe_ms[m] is not None),
+        else:       # should the peer-mapped run turn out inconsistent: the fastest library mode
+            fallback_mode = min((m for m in probe_ms if m not in ("xgmi", "xgmi2") and probe_ms[m] is not None),
                                 key=lambda m: probe_ms[m], default=None)
     else:
         trainer = build(mode)
@@ -340,7 +343,8 @@ def run_benchmark(args) -> Optional[dict]:
             result["async_mode"] = async_report
         if trial is not None:
             result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok",
-                                                       "async_ms_per_step", "async_loss", "error")
+                                                       "async_ms_per_step", "async_loss", "ok2", "ms_per_step2",
+                                                       "error", "error2")
                                              if k in trial}
     if hasattr(trainer, "close"):
         _sync(device, distributed)
