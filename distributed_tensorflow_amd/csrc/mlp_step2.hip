@@ -791,6 +791,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
           xdst[0] = p.oW2 + e;
         }
       }
+      DTF_STAMP2_AT(lin, 5);
       if (is_main && tk == 0) {
         __syncthreads();   // red is reused
         db1part += __shfl_xor(db1part, 16);
