@@ -121,8 +121,9 @@ int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, 
                              int rank, int world, int timeout_ms, void* stream);
 // Two-launch step of a synchronous replica whose backward exchanges per element (mlp_step2.hip, XgParams).
 typedef struct DtfXgDesc {
-  uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox of this step's slot: 8-byte words
-                                        //   [source rank * n + element], uncached memory, zero-initialised
+  uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox: 2 slots (even / odd exchange
+                                        //   numbers) of 8-byte words [source rank * n + element], uncached
+                                        //   memory, zero-initialised
   uint32_t* state;                      // 4 zero-initialised words in local memory
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row

@@ -547,12 +547,15 @@ constexpr int bwd16_smem_floats(int NA) { return bwd16_red_floats(NA) + 128 * kL
 // the values in rank order (bit-identical on every replica) and performs the in-place SGD update of the fused
 // mode.  An 8-byte aligned store arrives whole, so the number doubles as the arrival flag: no separate flag,
 // no wait for a write acknowledgement, no barrier of any kind; the added latency is one xGMI write.
-// Two inbox slots alternate with the step parity: a replica that has finished step s has received every peer's
-// step-s values, hence every peer's step s-1 launch -- the last reader of the slot step s+1 overwrites -- is over.
+// Two inbox slots alternate with the exchange number (not with anything the host tracks): a replica that has
+// finished exchange s has received every peer's values of s, hence every peer's launch of exchange s-1 -- the
+// last reader of the slot that exchange s+1 overwrites -- is over.
 struct XgParams {
-  uint64_t* inbox[DTF_XGMI_MAX_RANKS];    // this slot's inbox of every rank: word [source * n + element]
+  uint64_t* inbox[DTF_XGMI_MAX_RANKS];    // inbox of every rank, slot 0: word [source * n + element]; the slot
+                                          //   of odd exchange numbers follows `slot_words` words further on
   uint32_t* state;                        // [0] exchange number (bumped by the forward launch), [2] error
   long n;                                 // elements per source row
+  long slot_words;                        // world * n
   long offW1, offb1, offW2, offb2;        // element offsets of the four gradients inside a row
   int rank, world;
   long long timeout_ticks;
@@ -564,11 +567,13 @@ struct XgParams {
 template <int W>
 __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, long e, float own, int* failed) {
   const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
+  const long slot = (seq & 1u) ? x.slot_words : 0L;
 #pragma unroll
   for (int r = 0; r < W; ++r)
     if (r < x.world && r != x.rank)
-      __hip_atomic_store(x.inbox[r] + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const uint64_t* mine = x.inbox[x.rank] + e;
+      __hip_atomic_store(x.inbox[r] + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint64_t* mine = x.inbox[x.rank] + slot + e;
   uint64_t v[W];
   long long t0 = 0;
 #pragma unroll 1
@@ -1337,6 +1342,7 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   }
   a.state = x->state;
   a.n = x->n;
+  a.slot_words = x->n * (long)x->world;
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
   a.rank = x->rank;
   a.world = x->world;

@@ -423,10 +423,10 @@ class XgmiFusedTrainer(_BaseTrainer):
         offs = {role: self.layout.var_range[name][0] for role, name in
                 (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
                  ("b2", "biases/Variable_1"))}
-        self._xg_desc = [self.xg.step_descriptor(s, offs) for s in (0, 1)]
+        self._xg_desc = self.xg.step_descriptor(offs)
 
     def _one_step(self, batch_index: int):
-        self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc[self.engine.parity])
+        self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
 
     _capture = XgmiTowerTrainer._capture
     replica_checksum = XgmiTowerTrainer.replica_checksum

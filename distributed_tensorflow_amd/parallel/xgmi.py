@@ -276,7 +276,7 @@ class PeerShards:
 class PeerInbox:
     """Inboxes of the exchange that runs INSIDE the backward launch (``hb.mlp_step_xg``).
 
-    Every replica owns, in uncached memory, two slots (even / odd steps) of ``world`` rows of ``numel`` 8-byte
+    Every replica owns, in uncached memory, two slots (even / odd exchange numbers) of ``world`` rows of ``numel`` 8-byte
     words.  Row *s* of a replica's inbox is written by replica *s* only: one word {exchange number, value} per
     gradient element, stored straight into the peer's HBM; the owner polls its own inbox.  The number in the
     upper half of a word is the arrival flag of its lower half.
@@ -315,12 +315,12 @@ class PeerInbox:
                     self._mapped.append(self._ptrs[h["rank"]])
             dist.barrier(group=group)                  # nobody writes into an inbox that is not mapped yet
 
-    def step_descriptor(self, slot: int, offsets: dict) -> "hb.DtfXgDesc":
-        """Arguments of ``hb.mlp_step_xg`` for steps of parity ``slot``; ``offsets`` maps W1 / b1 / W2 / b2 to
-        the element offsets of their gradients inside a row."""
+    def step_descriptor(self, offsets: dict) -> "hb.DtfXgDesc":
+        """Arguments of ``hb.mlp_step_xg``; ``offsets`` maps W1 / b1 / W2 / b2 to the element offsets of their
+        gradients inside a row.  (The kernel picks the slot from the exchange number.)"""
         d = hb.DtfXgDesc()
         for r in range(self.world):
-            d.inbox[r] = self._ptrs[r] + (self.slot_bytes if slot & 1 else 0)
+            d.inbox[r] = self._ptrs[r]
         d.state = self.state.data_ptr()
         d.n = self.numel
         d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
