@@ -205,9 +205,21 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
             sv.start_queue_runners(sess, [chief_queue_runner])
         writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
         if flags.resident and sync:
-            print("note: synchronous replicas hand-shake with the chief every step and run on the per-batch tier; "
-                  "their device-resident form is `bench.py --mode sync` / parallel.replicas", flush=True)
-        if flags.resident and not sync:
+            from ..data import DeviceDataset
+            from ..parallel.ps_resident import PsSyncResidentTrainer
+
+            ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, flags.batch_size,
+                               seed=1000 + flags.task_index)
+            trainer = PsSyncResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)))
+            trainer.prepare(steps_hint=(ds.batches_per_epoch,))
+            print(trainer.describe(), flush=True)
+            result = run_resident_loop(trainer, mnist, flags, writer, begin_time)
+            if not trainer.healthy():
+                raise RuntimeError("a replica never delivered its gradients: the synchronous run is void")
+            if is_chief:
+                trainer.publish()           # the PS shards hold the trained variables again
+            trainer.close()
+        elif flags.resident and not sync:
             from ..data import DeviceDataset
             from ..parallel.ps_resident import PsResidentTrainer
 

@@ -184,6 +184,14 @@ class IpcVariableStore:
         torch.cuda.synchronize(self.device)
         self._c(0).set(INIT_KEY, b"1")
 
+    def publish(self, local: torch.Tensor):
+        """Overwrite the shards with ``local`` (a replica that was trained elsewhere); no initialisation side effects."""
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b > a:
+                self._params(k).copy_(local[a:b])
+        torch.cuda.synchronize(self.device)
+
     def write_all(self, local: torch.Tensor):
         self._request_allocation()
         for k in range(self.n):

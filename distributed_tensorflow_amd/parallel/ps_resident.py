@@ -16,8 +16,11 @@ processes of their own, each replaying its graphs — write the same shards conc
 wait for each other.  With the TCP transport the pull and the push cross the host, so the steps
 are issued eagerly (still without any per-step feed).
 
-Synchronous replicas need the chief's token per step, a host handshake, and stay on the
-per-batch tier; their device-resident counterpart is ``parallel.replicas.SyncShardTrainer``.
+Synchronous replicas (``tfdist_between_sync.py --resident``) take the other route,
+``PsSyncResidentTrainer``: the chief's accumulate / take_grad / token hand-shake of the per-batch tier is a
+host round trip per step, so the device-resident form keeps one replica of the variables per worker and
+exchanges gradients INSIDE the backward launch through peer-mapped HBM (``parallel/xgmi.py::PeerInbox``):
+the mean of N gradients applied once per step, bit-identical replicas, two launches per step.
 """
 from __future__ import annotations
 
@@ -106,3 +109,97 @@ class PsResidentTrainer(_BaseTrainer):
     def describe(self) -> str:
         return (f"between-graph async worker, device-resident: pull -> 2 launches -> one-sided SGD push "
                 f"({type(self.store).__name__}" + (", hipGraph chunks of %d)" % self.chunk if self.use_graph else ", eager)"))
+
+
+class PsSyncResidentTrainer(_BaseTrainer):
+    """Synchronous replicas started the reference's way, on the device-resident tier.
+
+    ``SyncReplicasOptimizer(replicas_to_aggregate = total_num_replicas = number of workers)`` means: one update
+    per N worker batches, with the mean of their gradients (tfdist_between_sync.py:65-68).  Here every worker
+    task keeps a replica of the variables (initialised from the PS shards the chief filled), all workers map
+    each other's inboxes over HIP-IPC — the handles travel through the control store of ps task 0, the tasks
+    share no ``torch.distributed`` group — and a step is the two-launch cross-replica step of
+    ``MLPEngine.step_xg``.  The replicas stay bit-identical; ``publish()`` (the chief calls it at the end of the
+    run and before a checkpoint) copies them back into the PS shards.  The workers must share a node.
+    """
+
+    name = "ps-sync-resident"
+
+    def __init__(self, sess, train_op, dataset, batch: int, chunk: int = 50, use_graph: bool = True,
+                 timeout_ms: int = 60000):
+        from ..optim import SyncReplicasOptimizer
+        from .xgmi import PeerInbox, StoreGroup
+
+        plan = sess._plan(train_op)
+        m = plan["mlp"]
+        if m is None:
+            raise ValueError("the device-resident tier needs the fused MLP plan (graph not recognised)")
+        opt = train_op.attrs["optimizer"]
+        if not isinstance(opt, SyncReplicasOptimizer):
+            raise ValueError("PsSyncResidentTrainer is for SyncReplicasOptimizer train ops")
+        self.sess, self.store = sess, sess.store
+        self.device = sess.device
+        if self.device.type != "cuda":
+            raise RuntimeError("the device-resident synchronous tier needs GPU workers")
+        self.ds = dataset
+        self.rank, self.world = sess.server.task_index, sess.server.num_workers
+        if opt.replicas_to_aggregate != self.world or opt.total_num_replicas != self.world:
+            raise ValueError("the resident synchronous tier aggregates every worker's gradient: "
+                             "replicas_to_aggregate and total_num_replicas must equal the number of workers")
+        self.chunk = max(1, int(chunk))
+        self.use_graph = bool(use_graph)
+        self.layout = sess.layout
+        self.params, self.grads = sess.theta, None
+        self.store.pull(self.params)                 # every replica starts from the chief's initial values
+        torch.cuda.synchronize(self.device)
+        names = {r: m[r].op_name for r in ("W1", "b1", "W2", "b2")}
+        self.global_step = self.layout.view(self.params, "global_step").view(1)
+        self.engine = MLPEngine({r: self.layout.view(self.params, n) for r, n in names.items()}, None,
+                                batch=batch, lr=float(opt.lr_value()), act=m["act"], global_step=self.global_step)
+        self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self._bound_set = getattr(dataset, "active", 0)
+        self.lr = self.engine.lr
+        self.steps_done = 0
+        self._graphs = {}
+        group = StoreGroup(sess.server.client("ps", 0), "sync-resident", self.rank, self.world)
+        self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
+                            timeout_ms=timeout_ms)
+        self._xg_desc = self.xg.step_descriptor({r: self.layout.var_range[n][0] for r, n in names.items()})
+
+    def _one_step(self, batch_index: int):
+        with span("step"):
+            self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
+
+    def _capture(self, pos: int, n: int, parity: int):
+        # Two warm-up steps (real exchanges, performed by every worker alike) that are rolled back.
+        snap = self._snapshot()
+        self.engine.reset_step_workspace(parity)
+        for _ in range(2):
+            self._one_step(pos)
+        torch.cuda.synchronize(self.device)
+        self._restore(snap)
+        self.engine.reset_step_workspace(parity)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for i in range(n):
+                self._one_step(pos + i)
+        self.engine.parity = parity
+        return graph
+
+    def healthy(self) -> bool:
+        return not self.xg.failed()
+
+    def publish(self):
+        """Copy this replica into the PS shards (chief: end of the run, before a checkpoint)."""
+        self.store.publish(self.params)
+
+    def close(self):
+        self._graphs.clear()
+        self.xg.close()
+
+    def describe(self) -> str:
+        return (f"between-graph sync worker {self.rank} of {self.world}, device-resident: replica per worker, gradient "
+                f"exchange inside the backward launch over peer-mapped HBM (mean of {self.world}, one update per "
+                f"{self.world} batches), 2 launches/step"
+                + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))

@@ -75,6 +75,10 @@ class LocalVariableStore:
     def pull(self, local: torch.Tensor, locked: bool = False):
         return  # the local slab is the storage
 
+    def publish(self, local: torch.Tensor):
+        if local.data_ptr() != self.slab.data_ptr():
+            self.slab.copy_(local)
+
     def write_all(self, local: torch.Tensor):
         if local.data_ptr() != self.slab.data_ptr():
             self.slab.copy_(local)
@@ -157,6 +161,14 @@ class RemoteVariableStore:
         tmp = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device)
         self.layout.initialize(tmp, seed)
         self.write_all(tmp)
+
+    def publish(self, local: torch.Tensor):
+        """Overwrite the shards with ``local`` (a replica that was trained elsewhere); no initialisation side effects."""
+        self._host_t.copy_(local)
+        for k in range(self.n):
+            a, b = self.layout.shard_range[k]
+            if b > a:
+                self._c(k).buf_write(SHARD_BUF, self._host[a:b])
 
     def write_all(self, local: torch.Tensor):
         self._create_buffers()

@@ -57,6 +57,51 @@ def _open(handle: bytes) -> int:
     return int(out.value)
 
 
+class StoreGroup:
+    """``all_gather_object`` / ``barrier`` over a task server's control store, for processes that were started
+    the reference's way (``--job_name/--task_index``) and share no ``torch.distributed`` group."""
+
+    def __init__(self, client, name: str, rank: int, world: int, timeout: float = 120.0):
+        self.client, self.name, self.rank, self.world, self.timeout = client, name, int(rank), int(world), timeout
+        self._round = 0
+        self._nbar = 0
+
+    def all_gather_object(self, out: list, obj) -> None:
+        import pickle
+
+        self._round += 1
+        base = f"__grp__/{self.name}/{self._round}/"
+        self.client.set(base + str(self.rank), pickle.dumps(obj))
+        for r in range(self.world):       # blobs written by the other tasks of this job
+            out[r] = pickle.loads(self.client.get(base + str(r), timeout=self.timeout))
+
+    def barrier(self) -> None:
+        self._nbar += 1
+        key = f"__grp__/{self.name}/barrier"
+        self.client.add(key, 1)
+        self.client.wait_ge(key, self.world * self._nbar, timeout=self.timeout)
+
+
+def _all_gather(group, obj, world: int) -> list:
+    out: List[Optional[dict]] = [None] * world
+    if hasattr(group, "all_gather_object"):
+        group.all_gather_object(out, obj)
+    else:
+        import torch.distributed as dist
+
+        dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def _barrier(group) -> None:
+    if hasattr(group, "barrier") and hasattr(group, "all_gather_object"):
+        group.barrier()
+    else:
+        import torch.distributed as dist
+
+        dist.barrier(group=group)
+
+
 class XgmiExchange:
     """Buffers and peer mappings of one replica.
 
@@ -300,11 +345,8 @@ class PeerInbox:
         self._ptrs = [0] * self.world
         self._ptrs[self.rank] = self._ptr
         if self.world > 1:
-            import torch.distributed as dist
-
-            everyone: List[Optional[dict]] = [None] * self.world
-            dist.all_gather_object(everyone, {"rank": self.rank, "handle": _export(self._ptr),
-                                              "bytes": self.slot_bytes}, group=group)
+            everyone = _all_gather(group, {"rank": self.rank, "handle": _export(self._ptr),
+                                           "bytes": self.slot_bytes}, self.world)
             with torch.cuda.device(self.device):
                 for h in everyone:
                     if h["rank"] == self.rank:
@@ -313,7 +355,7 @@ class PeerInbox:
                         raise RuntimeError("replicas disagree on the inbox size")
                     self._ptrs[h["rank"]] = _open(h["handle"])
                     self._mapped.append(self._ptrs[h["rank"]])
-            dist.barrier(group=group)                  # nobody writes into an inbox that is not mapped yet
+            _barrier(group)                            # nobody writes into an inbox that is not mapped yet
 
     def step_descriptor(self, offsets: dict) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_xg``; ``offsets`` maps W1 / b1 / W2 / b2 to the element offsets of their

@@ -137,6 +137,32 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
     assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
 
 
+@pytest.mark.parametrize("n_ps,n_w,transport", [(1, 2, "ipc"), (2, 2, "tcp")])
+def test_resident_sync_workers_exchange_inside_the_backward_launch(n_ps, n_w, transport, tmp_path):
+    """tfdist_between_sync.py --resident: a replica per worker process, gradients swapped through peer-mapped
+    inboxes (handles rendezvous over the ps control store), one update per n_w batches, identical workers."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.01", f"--transport={transport}", "--resident",
+            f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between_sync.py", n_ps, n_w, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    steps, costs, accs = [], [], []
+    for i in range(n_w):
+        out = res[f"worker{i}"][1]
+        assert "inside the backward launch" in out and "hipGraph chunks" in out, out[-2000:]
+        assert out.rstrip().endswith("Done")
+        steps.append([int(v) for v in re.findall(r"Step: (\d+),", out)])
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+        accs.append(re.findall(r"Test-Accuracy: ([\d.]+)", out))
+    assert steps[0] == steps[1] and steps[0][-1] == 2 * 22          # one update per n_w batches, in lock step
+    assert accs[0] == accs[1] and len(accs[0]) == 2                 # bit-identical replicas evaluate identically
+    assert all(c[-1] < c[0] for c in costs)
+
+
 def _single_trainer(double_buffer, pipelined, n=2200, batch=100, chunk=5):
     import numpy as np
 
