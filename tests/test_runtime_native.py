@@ -112,3 +112,36 @@ def test_crc32c_known_vectors():
     assert rt.crc32c(b"123456789") == 0xE3069283
     assert rt.crc32c(b"") == 0
     assert rt.crc32c(bytes(32)) == 0x8A9136AA
+
+
+def test_store_group_gathers_objects_and_synchronises_tasks(server):
+    """The rendezvous used by worker tasks that share no torch.distributed group (handles of peer-mapped buffers)."""
+    from distributed_tensorflow_amd.parallel.xgmi import StoreGroup
+
+    world, results, order = 3, {}, []
+
+    def task(rank):
+        g = StoreGroup(_client(server), "test", rank, world, timeout=10)
+        for round_no in range(2):                       # rounds do not mix
+            out = [None] * world
+            g.all_gather_object(out, {"rank": rank, "round": round_no, "blob": bytes([rank]) * 64})
+            results[(rank, round_no)] = out
+        if rank == 0:
+            time.sleep(0.3)
+        order.append(("before", rank))
+        g.barrier()
+        order.append(("after", rank))
+        g.barrier()
+
+    threads = [threading.Thread(target=task, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(20)
+        assert not t.is_alive()
+    for rank in range(world):
+        for round_no in range(2):
+            got = results[(rank, round_no)]
+            assert [o["rank"] for o in got] == [0, 1, 2] and all(o["round"] == round_no for o in got)
+            assert got[2]["blob"] == b"\x02" * 64
+    assert [kind for kind, _ in order[:world]] == ["before"] * world      # nobody passed before the slowest arrived
