@@ -40,8 +40,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5500)
     ap.add_argument("--warmup", type=int, default=550)
     ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "xgmi", "xgmi2", "xgmi_async", "auto"],
-                    help="N=1 default: single; N>1 default: auto = the faster of sync (PS shard per GPU, "
-                         "reduce-scatter/all-gather) and towers (all-reduce, replicated apply), probed before warm-up")
+                    help="N=1 default: single; N>1 default: auto = the fastest of sync (PS shard per GPU, RCCL "
+                         "reduce-scatter/all-gather), towers (RCCL all-reduce, replicated apply), xgmi (one exchange "
+                         "kernel over peer-mapped HBM) and xgmi2 (exchange inside the backward launch), probed before "
+                         "the warm-up; the peer-mapped ones only after their trial in child processes succeeded")
     ap.add_argument("--chunk", type=int, default=50, help="steps captured per hipGraph replay")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="run the PyTorch reference path on CPU (debug)")

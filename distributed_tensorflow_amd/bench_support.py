@@ -120,7 +120,7 @@ def run_benchmark(args) -> Optional[dict]:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         xgmi_ok, peer_async_ok, xgmi2_ok = (bool(int(v)) for v in flag.tolist())
         if rank == 0 and not xgmi_ok:
-            print(f"[bench] peer-mapped exchange not used on this node: {trial}", flush=True)
+            print(f"[bench] peer-mapped exchange not used on this node: {trial}", file=sys.stderr, flush=True)
 
     sizes = (55000, 5000, 10000) if not use_cpu else (5500, 100, 1000)
     mnist = read_data_sets("MNIST_data", one_hot=True, seed=0, sizes=sizes)
@@ -236,7 +236,8 @@ def run_benchmark(args) -> Optional[dict]:
         consistent = all(int(g[0]) == 1 and int(g[1]) == int(seen[0][1]) for g in seen)
         if not consistent and fallback_mode is not None:
             if rank == 0:
-                print("[bench] replicas disagree after the peer-mapped run; repeating with " + fallback_mode, flush=True)
+                print("[bench] replicas disagree after the peer-mapped run; repeating with " + fallback_mode,
+                      file=sys.stderr, flush=True)
             retire(trainer)
             mode, trainer = fallback_mode, build(fallback_mode)
             elapsed = timed(trainer)
