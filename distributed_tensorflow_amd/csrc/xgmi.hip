@@ -184,26 +184,25 @@ __device__ __forceinline__ float* shard_of(const ShardArgs& a, int owner) {
   return p;
 }
 
+// (32-bit vector indices: the host checks that the slab has fewer than 2^31 vectors; a 64-bit division per
+// thread would cost more than the copy)
 __global__ __launch_bounds__(kBlock) void shard_pull_kernel(ShardArgs a, float* __restrict__ local) {
-  const int64_t nvec = a.n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const unsigned nvec = (unsigned)(a.n >> 2), cvec = (unsigned)(a.chunk >> 2);
+  const unsigned stride = gridDim.x * kBlock;
   f32x4* l4 = reinterpret_cast<f32x4*>(local);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-    const int owner = (int)((i << 2) / a.chunk);
-    l4[i] = reinterpret_cast<const f32x4*>(shard_of(a, owner))[i];
-  }
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride)
+    l4[i] = reinterpret_cast<const f32x4*>(shard_of(a, (int)(i / cvec)))[i];
 }
 
 __global__ __launch_bounds__(kBlock) void shard_push_sgd_kernel(ShardArgs a, const float* __restrict__ grad,
                                                                 const float* __restrict__ lr_ptr, int64_t step_index) {
   const float lr = *lr_ptr;
-  const int64_t nvec = a.n >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const unsigned nvec = (unsigned)(a.n >> 2), cvec = (unsigned)(a.chunk >> 2);
+  const unsigned stride = gridDim.x * kBlock;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(grad);
-  const int64_t step_vec = step_index >= 0 ? (step_index >> 2) : -1;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-    const int owner = (int)((i << 2) / a.chunk);
-    float* dst = shard_of(a, owner);
+  const unsigned step_vec = step_index >= 0 ? (unsigned)(step_index >> 2) : 0xffffffffu;
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    float* dst = shard_of(a, (int)(i / cvec));
     const f32x4 g = g4[i];
     if (i != step_vec) {
       f32x4* d4 = reinterpret_cast<f32x4*>(dst);
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void shard_push_sgd_kernel(ShardArgs a, con
     } else {
       // the vector that holds global_step: the counter is only ever touched by the atomic below
       for (int c = 0; c < 4; ++c) {
-        const int64_t e = (i << 2) + c;
+        const int64_t e = ((int64_t)i << 2) + c;
         if (e != step_index) dst[e] -= lr * g[c];
       }
       __hip_atomic_fetch_add(dst + step_index, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -342,7 +341,8 @@ extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* p
 
 static int fill_shards(ShardArgs& a, const uint64_t* shards, int world, int64_t chunk) {
   if (!shards) return DTF_ERR_NULL;
-  if (world < 1 || world > kMaxRanks || chunk <= 0 || (chunk & 3)) return DTF_ERR_SHAPE;
+  if (world < 1 || world > kMaxRanks || chunk <= 0 || (chunk & 3) || chunk * world >= (int64_t(1) << 33))
+    return DTF_ERR_SHAPE;
   for (int r = 0; r < kMaxRanks; ++r) {
     a.shard[r] = r < world ? reinterpret_cast<float*>(shards[r]) : nullptr;
     if (r < world && (!a.shard[r] || !aligned16(a.shard[r]))) return DTF_ERR_NULL;
