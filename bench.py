@@ -44,7 +44,8 @@ def parse_args():
                          "reduce-scatter/all-gather), towers (RCCL all-reduce, replicated apply), xgmi (one exchange "
                          "kernel over peer-mapped HBM) and xgmi2 (exchange inside the backward launch), probed before "
                          "the warm-up; the peer-mapped ones only after their trial in child processes succeeded")
-    ap.add_argument("--chunk", type=int, default=50, help="steps captured per hipGraph replay")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="steps captured per hipGraph replay (0 = a whole 550-step epoch for one GPU, 50 otherwise)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu", action="store_true", help="run the PyTorch reference path on CPU (debug)")
     return ap.parse_args()
