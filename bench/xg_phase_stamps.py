@@ -1,5 +1,11 @@
+"""Phase stamps (ns, thread 0 of one workgroup) of the backward launch with ONE replica: the plain fused backward
+(`single`, two launches per step) next to the cross-replica one (`xgmi2`), for a main tile workgroup, another one and
+the statistics workgroup.  Shows what the exchange machinery costs before any peer traffic.
+
+    python bench/xg_phase_stamps.py
+"""
 import ctypes as C, sys, os, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.data import DeviceDataset
 from distributed_tensorflow_amd.ops import hip_backend as hb
 from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
