@@ -463,9 +463,22 @@ class Session:
             eng._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
             eng.loss_hist, eng.acc_hist = eng._stats[0:1], eng._stats[1:2]
             K, C = params["W1"].shape[0], params["W2"].shape[1]
-            eng._x_stage = torch.zeros((batch, K), dtype=torch.float32, device=self.device)
-            eng._y_stage = torch.zeros((batch, C), dtype=torch.float32, device=self.device)
+            # the fed batch travels as ONE host-to-device copy: x and y side by side in a pinned host buffer
+            # (reused every step: the step's blocking statistics fetch orders it after the copy) and in one
+            # device buffer the kernels read through two views
+            stage = torch.zeros(batch * (K + C), dtype=torch.float32, device=self.device)
+            eng._stage_dev = stage
+            eng._x_stage = stage[: batch * K].view(batch, K)
+            eng._y_stage = stage[batch * K:].view(batch, C)
+            eng._stage_host = None
+            if self.device.type == "cuda" and (batch * K) % 4 == 0:
+                host = torch.zeros(batch * (K + C), dtype=torch.float32).pin_memory()
+                eng._stage_host = host
+                eng._stage_host_x = host[: batch * K].view(batch, K).numpy()
+                eng._stage_host_y = host[batch * K:].view(batch, C).numpy()
             eng.bind_data(eng._x_stage, eng._y_stage, batches_per_epoch=1)
+            # a local session applies plain SGD inside the step's own two launches (no separate optimizer launch)
+            eng.global_step = None
             self._engines[key] = eng
         return eng
 
@@ -473,6 +486,11 @@ class Session:
         x, y = feed.get(m["x"]), feed.get(m["y_"])
         if x is None or y is None:
             raise ValueError("both input placeholders must be fed")
+        if eng._stage_host is not None and not isinstance(x, torch.Tensor) and not isinstance(y, torch.Tensor):
+            np.copyto(eng._stage_host_x, x, casting="same_kind")
+            np.copyto(eng._stage_host_y, y, casting="same_kind")
+            eng._stage_dev.copy_(eng._stage_host, non_blocking=True)
+            return
         xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         yt = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
         eng._x_stage.copy_(xt, non_blocking=True)
@@ -498,6 +516,7 @@ class Session:
         m = plan["mlp"]
         lr = opt.lr_value()
         sync = isinstance(opt, SyncReplicasOptimizer) and self.store.is_remote
+        applied = False
         if m is not None and m["x"] in feed:
             xv = feed[m["x"]]
             batch = int(xv.shape[0])
@@ -505,7 +524,13 @@ class Session:
             with span("stage"):
                 self._stage(eng, m, feed)
             with span("step"):
-                eng.step_grad(0, 1.0)
+                if not self.store.is_remote:
+                    # no parameter server: the SGD update happens inside the step's two launches
+                    self._bind_local_update(eng, train_op, lr)
+                    eng.step_fused(0)
+                    applied = True
+                else:
+                    eng.step_grad(0, 1.0)
             with span("fetch_stats"):
                 host = eng._stats.cpu()          # the step's only wait for the device
             cache[m["loss"]] = host[0]
@@ -528,6 +553,8 @@ class Session:
                 cache[k] = val.detach() if isinstance(val, torch.Tensor) else val
             self.generic_steps += 1
         # ---- push ----
+        if applied:
+            return
         if sync:
             if not self._local_step_ready:
                 self.store.sync_local_step()
@@ -544,6 +571,17 @@ class Session:
             with span("push_apply"):
                 self.store.push_apply(self.grad, lr, opt.use_locking,
                                       bump_step=train_op.attrs["global_step"] is not None)
+
+    def _bind_local_update(self, eng: MLPEngine, train_op, lr: float):
+        """Point the engine's fused step at this train op's learning rate and step counter (cached per engine)."""
+        gs_var = train_op.attrs["global_step"]
+        key = (float(lr), id(gs_var))
+        if getattr(eng, "_local_update_key", None) == key:
+            return
+        eng.set_lr(lr)
+        eng.global_step = None if gs_var is None else self._var_view(gs_var).view(1)
+        eng._desc = None
+        eng._local_update_key = key
 
     def _init_tokens(self, node):
         opt = node.attrs["optimizer"]

@@ -66,13 +66,10 @@ def test_cluster_spec():
 
 
 def test_server_roles_and_bad_job():
-    import socket
+    from cluster_utils import free_ports
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cluster = {"ps": [f"localhost:{port}"], "worker": [f"localhost:{port + 1}"]}
+    port, wport = free_ports(2)           # two ports known to be free (port + 1 may belong to somebody else)
+    cluster = {"ps": [f"localhost:{port}"], "worker": [f"localhost:{wport}"]}
     with pytest.raises(ValueError):
         Server(cluster, job_name="", task_index=0)
     srv = Server(cluster, job_name="ps", task_index=0, config=ConfigProto(allow_soft_placement=True))
