@@ -27,7 +27,7 @@ def main(_):
         device = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
         ds = DeviceDataset(mnist.train.images, mnist.train.labels, device, FLAGS.batch_size, seed=0)
         trainer = build_replica_trainer(mode="single", device=device, dataset=ds, batch=FLAGS.batch_size,
-                                        lr=FLAGS.lr, seed=1, chunk=min(FLAGS.freq, 50), act=FLAGS.activation)
+                                        lr=FLAGS.lr, seed=1, chunk=min(FLAGS.freq, 550), act=FLAGS.activation)
         print("Ready to go")
         writer = tf.summary.FileWriter(FLAGS.logs_path) if FLAGS.summaries else None
         mnist_mlp.run_resident_loop(trainer, mnist, FLAGS, writer, begin_time)
