@@ -4,6 +4,9 @@
 //     launch 1  fwd_tile8 / fwd_tile16   a2 = act(x W1 + b1), logit partials      (F1-F3, part of F4)
 //     launch 2  bwd_tile16               logits, softmax-xent, accuracy, dz3, dW2, db2, dz2, db1, dW1
 //                                        and (fused mode) the SGD update          (F4-F12, G1-G7, U1-U2)
+//   two launches, synchronous replicas on several GPUs (dtf_mlp_step_xg)
+//     launch 2' bwd_tile16_xg            launch 2 in fused mode whose threads first swap their gradient
+//                                        element with the same thread of every peer replica (see XgParams)
 //   one launch per step (fused single-GPU training; dtf_mlp_chunk_pipelined)
 //     step_pipe                          launch 2 of step t ++ launch 1 of step t+1, see its comment
 // (op numbers: the reference graph, tfdist_between.py:55-70).
