@@ -264,8 +264,10 @@ def run_benchmark(args) -> Optional[dict]:
         async_report = {"value": round(n * BATCH * 1000.0 / ms, 1), "unit": "samples/s", "ms_per_step": ms,
                         "steps": STEPS_PER_EPOCH, "global_step": trial.get("async_global_step"),
                         "every_push_counted": True, "measured_in": "trial child processes",
-                        "parallelism": f"async PS dp{n}: shard per GPU in HBM, one-sided pull and lock-free SGD "
-                                       f"push through peer mappings, no barrier"}
+                        "parallelism": f"async PS dp{n}: shard per GPU in HBM, one-sided pull and lock-free SGD push "
+                                       + ("inside the backward launch (float atomics), 3 launches/step, "
+                                          if trial.get("async_fused_push", False) else "as a launch, 4 launches/step, ")
+                                       + "through peer mappings, no barrier"}
     elif not use_cpu and not distributed and mode != "xgmi_async" and os.environ.get("DTF_BENCH_ASYNC", "1") != "0":
         try:
             a_steps = min(steps, 4 * STEPS_PER_EPOCH)
@@ -348,7 +350,7 @@ def run_benchmark(args) -> Optional[dict]:
         if async_report is not None:
             result["async_mode"] = async_report
         if trial is not None:
-            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok",
+            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok", "async_fused_push",
                                                        "async_ms_per_step", "async_loss", "ok2", "ms_per_step2",
                                                        "error", "error2")
                                              if k in trial}

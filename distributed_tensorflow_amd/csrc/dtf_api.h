@@ -128,7 +128,11 @@ typedef struct DtfXgDesc {
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
   int32_t rank, world, timeout_ms, reserved;
+  int64_t step_index;                   // dtf_mlp_step_async only: element that holds global_step (< 0: none)
 } DtfXgDesc;
+// Asynchronous worker step: inbox[k] = base of rank k's slab-sized shard buffer, n = floats per shard; the
+// backward pushes `shard_owner(e)[e] -= lr * g` with float atomics through the mappings and counts the push.
+int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream);
 int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
                     void* stream);
 

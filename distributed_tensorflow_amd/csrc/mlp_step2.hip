@@ -560,6 +560,7 @@ struct XgParams {
   long n;                                 // elements per source row
   long slot_words;                        // world * n
   long offW1, offb1, offW2, offb2;        // element offsets of the four gradients inside a row
+  long chunk, step_index;                 // asynchronous variant only (see xa_push): floats per shard, global_step
   int rank, world;
   long long timeout_ticks;
 };
@@ -607,11 +608,24 @@ __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, lo
   return total;
 }
 
+// Asynchronous variant (XW < 0): the same per-thread outputs are not swapped but PUSHED -- each gradient element is
+// applied where the variable lives, `shard_owner(e)[e] -= lr * g`, as one fire-and-forget float atomic through
+// the peer mapping (x.inbox[k] then holds the base of rank k's slab-sized shard buffer).  No worker waits for
+// anything: the lock-free parameter-server update of the reference (tfdist_between.py:65-66) without a launch
+// of its own, and, being atomic, without lost updates.
+__device__ __forceinline__ void xa_push(const XgParams& x, long e, float delta) {
+  const unsigned owner = (unsigned)e / (unsigned)x.chunk;
+  uint64_t* base = x.inbox[0];
+  for (int k = 1; k < x.world; ++k) base = (owner == (unsigned)k) ? x.inbox[k] : base;
+  (void)__hip_atomic_fetch_add(reinterpret_cast<float*>(base) + e, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int NS, int CQ, int NA, bool YV2, int XW = 0>
 __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin,
                                                 const XgParams* xg = nullptr) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
-  constexpr bool XG = XW > 0;             // cross-replica variant for up to XW replicas
+  constexpr bool XG = XW != 0;            // cross-replica variants: XW > 0 synchronous exchange among up to XW
+                                          // replicas, XW < 0 asynchronous push into the parameter shards
   constexpr int kTileRows = 16 * NA;
   float* red = smem;                         // [8 waves][4 NA][64] partial tiles (phase 2+)
   float* zs = smem;                          // [128][17] logits    (phase 1, aliases red)
@@ -693,7 +707,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   // very end of the statistics block (which finishes last); any valid address when there is none
   const float gs_old = *(p.global_step ? p.global_step : p.lr);
   unsigned xg_seq = 0u, xg_poisoned = 0u;
-  if constexpr (XG) {
+  if constexpr (XW > 0) {
     // number of this exchange: bumped by the forward launch of the same step (one writer, earlier launch);
     // both words are consumed at the exchange only, so their latency hides behind everything in between
     xg_seq = xg->state[0];
@@ -908,7 +922,14 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
       DTF_STAMP2_AT(lin, 6);
     }
   }
-  if constexpr (XG) {
+  if constexpr (XW < 0) {
+    const XgParams& x = *xg;
+#pragma unroll 1
+    for (int item = 0; item < 2; ++item)
+      if (xv[item]) xa_push(x, xe[item], -lr * xown[item]);
+    if (stats_block && tid == 0 && x.step_index >= 0) xa_push(x, x.step_index, 1.0f);
+  }
+  if constexpr (XW > 0) {
     const XgParams& x = *xg;
     const unsigned seq = xg_seq;
     if (xg_poisoned == 0u) {                 // after a failed exchange nothing is sent and nothing applied
@@ -1228,7 +1249,7 @@ bool dtf_step2_supported(int B, int K, int H, int C) {
 // into; consecutive steps MUST alternate it (the other half is cleared for the
 // next step by the forward launch).
 static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
-                             hipStream_t stream, XgParams* xg) {
+                             hipStream_t stream, XgParams* xg, bool xg_async = false) {
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
   if (!dtf_step2_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
   const bool fused = mode == DTF_HEAD_FUSED;
@@ -1247,8 +1268,8 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
 #define DTF_FWD8_ARGS                                                                                 \
   dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}, \
-      (xg ? xg->state : (unsigned*)nullptr)
-  if (xg && !tile8) return DTF_ERR_UNSUPPORTED;      // the exchange is numbered by the 8x8 forward's duty workgroup
+      (xg && !xg_async ? xg->state : (unsigned*)nullptr)
+  if (xg && !xg_async && !tile8) return DTF_ERR_UNSUPPORTED;   // the exchange is numbered by the 8x8 forward's duty workgroup
   if (tile8 && ns8 == 2) {
     hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_FWD8_ARGS);
   } else if (tile8 && ns8 == 1) {
@@ -1305,7 +1326,8 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
     if (fast) hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true, W>), grid, block, 0, stream, p, *xg);  \
     else hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false, W>), grid, block, 0, stream, p, *xg);      \
   } while (0)
-    if (xg->world <= 2) DTF_XG_LAUNCH(2);
+    if (xg_async) DTF_XG_LAUNCH(-1);
+    else if (xg->world <= 2) DTF_XG_LAUNCH(2);
     else if (xg->world <= 4) DTF_XG_LAUNCH(4);
     else if (xg->world <= 8) DTF_XG_LAUNCH(8);
     else DTF_XG_LAUNCH(16);
@@ -1316,6 +1338,35 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 4, false>), grid, block, 0, stream, p);
   }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// Step of an asynchronous worker: forward, then a backward that pushes every gradient element into the shard
+// that owns it (x->inbox[k] = base of rank k's slab-sized shard buffer, x->n = floats per shard) and counts the
+// push in global_step (x->step_index, < 0: not counted).  Two launches; see xa_push.
+extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream) {
+  if (!d || !x) return DTF_ERR_NULL;
+  if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
+  if (x->world < 1 || x->world > DTF_XGMI_MAX_RANKS || x->n <= 0 || (x->n & 3)) return DTF_ERR_SHAPE;
+  if (!d->gW1 || !d->gb1 || !d->gW2 || !d->gb2) return DTF_ERR_NULL;     // valid (unused) gradient locations
+  const long K = d->in_dim, H = d->hidden, C = d->classes, total = x->n * x->world;
+  if (total >= (1L << 32) || x->step_index >= total || x->offW1 < 0 || x->offW1 + K * H > total || x->offb1 < 0 ||
+      x->offb1 + H > total || x->offW2 < 0 || x->offW2 + H * C > total || x->offb2 < 0 || x->offb2 + C > total)
+    return DTF_ERR_SHAPE;
+  XgParams a;
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+    a.inbox[r] = r < x->world ? reinterpret_cast<uint64_t*>(x->inbox[r]) : nullptr;
+    if (r < x->world && !a.inbox[r]) return DTF_ERR_NULL;
+  }
+  a.state = nullptr;
+  a.n = 0;
+  a.slot_words = 0;
+  a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
+  a.chunk = x->n;
+  a.step_index = x->step_index;
+  a.rank = x->rank;
+  a.world = x->world;
+  a.timeout_ticks = 0;
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true);
 }
 
 int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
@@ -1347,6 +1398,8 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   a.n = x->n;
   a.slot_words = x->n * (long)x->world;
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
+  a.chunk = 0;
+  a.step_index = -1;
   a.rank = x->rank;
   a.world = x->world;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock

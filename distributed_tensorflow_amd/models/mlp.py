@@ -282,6 +282,15 @@ class MLPEngine:
         hb.mlp_step_xg(self._descriptor(), self._bi(batch_index), self.parity, scale, xg)
         self.parity ^= 1
 
+    def step_async(self, batch_index: Optional[int], shards: "hb.DtfXgDesc"):
+        """Step of an asynchronous worker: forward, then a backward whose threads apply ``-lr * g`` of their own
+        gradient element directly to the parameter shard that owns it (``PeerShards.step_descriptor``).  The
+        engine's own parameters are only read; the caller refreshes them with a pull."""
+        if not self.on_gpu:
+            raise RuntimeError("the shard-pushing step is a GPU path")
+        hb.mlp_step_async(self._descriptor(), self._bi(batch_index), self.parity, shards)
+        self.parity ^= 1
+
     def advance(self, n: int = 1):
         self._host_cursor += n
 

@@ -89,6 +89,7 @@ class DtfXgDesc(C.Structure):
         ("world", C.c_int32),
         ("timeout_ms", C.c_int32),
         ("reserved", C.c_int32),
+        ("step_index", C.c_int64),
     ]
 
 
@@ -116,6 +117,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_allreduce_apply.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
     lib.dtf_mlp_step_xg.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, C.POINTER(DtfXgDesc), vp]
     lib.dtf_mlp_step_xg.restype = C.c_int
+    lib.dtf_mlp_step_async.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, C.POINTER(DtfXgDesc), vp]
+    lib.dtf_mlp_step_async.restype = C.c_int
     lib.dtf_enable_peer_access.argtypes = [i32, i32]
     lib.dtf_enable_peer_access.restype = C.c_int
     lib.dtf_xgmi_pull.argtypes = [vp, i32, i64, vp, vp]
@@ -312,6 +315,12 @@ def mlp_chunk_pipelined_supported(B: int, K: int, H: int, Cn: int) -> bool:
 def mlp_step_grad(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float = 1.0):
     _check(require().dtf_mlp_step_grad(C.byref(desc), int(batch_index), int(parity), float(grad_scale),
                                        _stream()), "dtf_mlp_step_grad")
+
+
+def mlp_step_async(desc: DtfMlpDesc, batch_index: int, parity: int, xg: DtfXgDesc):
+    """Forward + a backward that pushes ``shard -= lr * g`` element-wise into the shards described by ``xg``."""
+    _check(require().dtf_mlp_step_async(C.byref(desc), int(batch_index), int(parity), C.byref(xg), _stream()),
+           "dtf_mlp_step_async")
 
 
 def mlp_step_xg(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float, xg: DtfXgDesc):

@@ -446,9 +446,12 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
         pull   every shard -> private slab        (1 launch, remote shards over xGMI)
         fwd + bwd on the worker's own mini-batch   (2 launches)
-        push   shard -= lr * g on every shard      (1 launch, in place through the mappings, global_step += 1)
+        push   shard -= lr * g on every shard      (in place through the mappings, global_step += 1)
 
-    with no barrier, flag or matching receive anywhere: workers run at their own pace against whatever the
+    The push is either a launch of its own (read-modify-write of whole vectors, 4 launches per step) or, with
+    ``fused_push`` (the default), part of the backward launch: every backward thread applies ``-lr * g`` of its
+    own gradient element to the owning shard as one fire-and-forget float atomic (``dtf_mlp_step_async``,
+    3 launches per step, and concurrent pushes of several workers lose no update).  Either way there is no barrier, flag or matching receive anywhere: workers run at their own pace against whatever the
     shards hold when they pull, and concurrent pushes interleave without a lock — the reference's default
     (GradientDescentOptimizer, use_locking=False, tfdist_between.py:65-66).  ``global_step`` counts every
     worker's push, so it advances by N per "round" (README.md:70-72 of the reference observes the same).
@@ -456,13 +459,14 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
     name = "xgmi_async"
 
-    def __init__(self, *a, group=None, **kw):
+    def __init__(self, *a, group=None, fused_push: bool = True, **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("the peer-mapped shards are a GPU path")
         from .xgmi import PeerShards
 
         self.group = group
+        self.fused_push = bool(fused_push)
         chunk = self.layout.shard_numel(0)
         self.shards = PeerShards(self.rank, self.world, chunk, self.device, group=group)
         if self.shards.total != self.params.numel():
@@ -476,10 +480,27 @@ class XgmiAsyncTrainer(_BaseTrainer):
         self.shards.push_sgd(self.grads, zero_lr, -1)
         torch.cuda.synchronize(self.device)
         self.engine.reset_step_workspace(0)
+        if self.fused_push:
+            offs = {role: self.layout.var_range[name][0] for role, name in
+                    (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
+                     ("b2", "biases/Variable_1"))}
+            self._push_desc = self.shards.step_descriptor(offs, self.step_index)
+            # same for the pushing backward: the engine reads lr from its own tensor, so a zero there for one step
+            dry = self.shards.step_descriptor(offs, -1)
+            keep = self.engine.lr.clone()
+            self.engine.lr.zero_()
+            self.engine.step_async(0, dry)
+            self.engine.lr.copy_(keep)
+            torch.cuda.synchronize(self.device)
+            self.engine.reset_step_workspace(0)
 
     def _one_step(self, batch_index: int):
         with span("pull"):
             self.shards.pull(self.params)
+        if self.fused_push:
+            with span("step_push_apply"):
+                self.engine.step_async(batch_index, self._push_desc)
+            return
         with span("step"):
             self.engine.step_grad(batch_index, 1.0)
         with span("push_apply"):
@@ -509,8 +530,11 @@ class XgmiAsyncTrainer(_BaseTrainer):
         self.shards.close()
 
     def describe(self):
-        return (f"async PS dp{self.world}: shard per GPU in HBM, one-sided pull (1 launch) -> 2 launches -> "
-                f"one-sided lock-free SGD push (1 launch) through peer mappings, no barrier"
+        push = ("forward -> backward that pushes -lr*g per element into the owning shard with float atomics "
+                "(3 launches/step)" if self.fused_push else
+                "2 launches -> one-sided lock-free SGD push (1 launch)")
+        return (f"async PS dp{self.world}: shard per GPU in HBM, one-sided pull (1 launch) -> {push} "
+                f"through peer mappings, no barrier"
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
 

@@ -112,31 +112,38 @@ def main(argv=None) -> int:
             out["ok2"] = False
             out["error2"] = f"{type(e).__name__}: {e}"
         print(json.dumps(out), flush=True)
-        # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes
-        ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
-                                   rank=args.rank, world=args.world, chunk=args.chunk, use_graph=True)
-        loss0, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
-        ta.prepare((args.steps, args.steps))
-        dist.barrier()
-        ta.run_steps(args.steps)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t0 = time.perf_counter()
-        ta.run_steps(args.steps)
-        torch.cuda.synchronize(dev)
-        dta = time.perf_counter() - t0
-        dist.barrier()                                    # every worker's pushes have landed
-        gs = ta.global_step_value()
-        loss1, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
-        a_fin = bool(torch.isfinite(ta.params).all())
-        times = [None] * args.world
-        dist.all_gather_object(times, (dta, a_fin and gs == 2 * args.steps * args.world and loss1 <= loss0))
-        out.update(async_ok=all(x[1] for x in times), async_global_step=gs,
-                   async_ms_per_step=round(1000.0 * max(x[0] for x in times) / args.steps, 5),
-                   async_loss=[round(loss0, 4), round(loss1, 4)])
-        note(f"async ok={out['async_ok']} {out['async_ms_per_step']} ms/step")
-        dist.barrier()
-        ta.close()
+        # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes; first with
+        # the push inside the backward launch (float atomics through the mappings), then, should that not hold
+        # here (a push lost or not counted), with the push as a launch of its own
+        for fused_push in (True, False):
+            ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
+                                       rank=args.rank, world=args.world, chunk=args.chunk, use_graph=True,
+                                       fused_push=fused_push)
+            loss0, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
+            ta.prepare((args.steps, args.steps))
+            dist.barrier()
+            ta.run_steps(args.steps)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            ta.run_steps(args.steps)
+            torch.cuda.synchronize(dev)
+            dta = time.perf_counter() - t0
+            dist.barrier()                                    # every worker's pushes have landed
+            gs = ta.global_step_value()
+            loss1, _ = ta.evaluate(ds.x_epoch[:2000], ds.y_epoch[:2000])
+            a_fin = bool(torch.isfinite(ta.params).all())
+            times = [None] * args.world
+            dist.all_gather_object(times, (dta, a_fin and gs == 2 * args.steps * args.world and loss1 <= loss0))
+            out.update(async_ok=all(x[1] for x in times), async_global_step=gs, async_fused_push=fused_push,
+                       async_ms_per_step=round(1000.0 * max(x[0] for x in times) / args.steps, 5),
+                       async_loss=[round(loss0, 4), round(loss1, 4)])
+            note(f"async (push {'inside the backward' if fused_push else 'as a launch'}) ok={out['async_ok']} "
+                 f"{out['async_ms_per_step']} ms/step")
+            dist.barrier()
+            ta.close()
+            if out["async_ok"]:
+                break
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer: "do not use this path here"
         out["error"] = f"{type(e).__name__}: {e}"

@@ -1,6 +1,6 @@
 """One replica of the peer-mapped exchange test (several of these share the GPU).
 
-usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|async]
+usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|async|async_sep]
 Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference
 (sync), or the state of the shared shards after every worker finished (async).
 """
@@ -18,9 +18,9 @@ from distributed_tensorflow_amd.ops import reference as ref         # noqa: E402
 from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer  # noqa: E402
 
 
-def run_async(rank, world, steps, use_graph, dev, ds, B, lr):
+def run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=True):
     t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
-                              chunk=3, use_graph=bool(use_graph))
+                              chunk=3, use_graph=bool(use_graph), fused_push=fused_push)
     p0 = t.params.clone()
     loss0, _ = t.evaluate(ds.x_epoch, ds.y_epoch)
     t.prepare((steps,))
@@ -54,8 +54,8 @@ def main():
     x = torch.rand(rows, 784, generator=g)
     y = torch.eye(10)[torch.randint(0, 10, (rows,), generator=g)]
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
-    if mode == "async":
-        return run_async(rank, world, steps, use_graph, dev, ds, B, lr)
+    if mode in ("async", "async_sep"):
+        return run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=mode == "async")
     t = build_replica_trainer("xgmi2" if mode == "sync2" else "xgmi", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
                               chunk=3, use_graph=bool(use_graph), timeout_ms=30000,
                               **({} if mode == "sync2" else {"uncached_grads": bool(uncached)}))

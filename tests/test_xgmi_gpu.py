@@ -59,15 +59,47 @@ def test_replicas_stay_bit_identical_and_track_the_mean_gradient_reference(world
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,use_graph", [(2, False), (3, True)])
-def test_async_workers_update_shared_shards_one_sidedly(world, use_graph):
+@pytest.mark.parametrize("world,use_graph,mode", [(2, False, "async"), (3, True, "async"), (4, True, "async"),
+                                                  (2, True, "async_sep")])
+def test_async_workers_update_shared_shards_one_sidedly(world, use_graph, mode):
+    """``async``: the push is part of the backward launch (float atomics per element); ``async_sep``: a launch of
+    its own."""
     steps = 8
-    res = _run_replicas(world, steps, use_graph, mode="async")
+    res = _run_replicas(world, steps, use_graph, mode=mode)
     for r in res:
         assert r["finite"] and r["identical"], r              # after the last push everybody pulls the same shards
         assert r["global_step"] == world * steps, r           # every push counted, atomically
         assert r["moved"] > 1e-3 and r["loss_after"] < r["loss_before"], r
-        assert "one-sided" in r["describe"]
+        assert ("float atomics" if mode == "async" else "one-sided lock-free SGD push") in r["describe"]
+
+
+@pytest.mark.gpu
+def test_one_async_worker_trains_the_same_with_either_push():
+    """With a single worker nothing is concurrent, so the push inside the backward launch and the push kernel
+    must produce the same variables: ``shard + (-lr * g)`` either way."""
+    import torch
+
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(800, 784, generator=g)
+    y = torch.eye(10)[torch.randint(0, 10, (800,), generator=g)]
+    out = {}
+    for fused in (True, False):
+        ds = DeviceDataset(x, y, dev, 100, seed=5)
+        t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.05, seed=1, rank=0, world=1,
+                                  chunk=4, use_graph=fused, fused_push=fused)
+        p0 = t.params.clone()
+        t.prepare((12,))
+        t.run_steps(12)
+        torch.cuda.synchronize()
+        assert t.global_step_value() == 12
+        out[fused] = t.params.clone()
+        assert float((out[fused] - p0)[4:].abs().max()) > 1e-3
+        t.close()
+    assert torch.allclose(out[True], out[False], rtol=0, atol=1e-6), float((out[True] - out[False]).abs().max())
 
 
 @pytest.mark.gpu
