@@ -350,7 +350,7 @@ def run_benchmark(args) -> Optional[dict]:
         if async_report is not None:
             result["async_mode"] = async_report
         if trial is not None:
-            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok", "async_fused_push",
+            result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok", "async_fused_push", "async_ms_per_step_by_push",
                                                        "async_ms_per_step", "async_loss", "ok2", "ms_per_step2",
                                                        "error", "error2")
                                              if k in trial}

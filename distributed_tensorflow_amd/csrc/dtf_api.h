@@ -129,9 +129,11 @@ typedef struct DtfXgDesc {
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
   int32_t rank, world, timeout_ms, reserved;
   int64_t step_index;                   // dtf_mlp_step_async only: element that holds global_step (< 0: none)
+  int64_t shard_start[DTF_XGMI_MAX_RANKS + 1];   // dtf_mlp_step_async with n == 0: slab range of every shard
 } DtfXgDesc;
-// Asynchronous worker step: inbox[k] = base of rank k's slab-sized shard buffer, n = floats per shard; the
-// backward pushes `shard_owner(e)[e] -= lr * g` with float atomics through the mappings and counts the push.
+// Asynchronous worker step: the backward pushes `shard_owner(e)[e] -= lr * g` with float atomics through the
+// mappings and counts the push.  n > 0: equal shards of n floats, inbox[k] = base of rank k's slab-sized buffer;
+// n == 0: shard k = slab elements [shard_start[k], shard_start[k+1]), inbox[k] = address of its first element.
 int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream);
 int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
                     void* stream);

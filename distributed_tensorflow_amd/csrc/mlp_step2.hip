@@ -560,7 +560,8 @@ struct XgParams {
   long n;                                 // elements per source row
   long slot_words;                        // world * n
   long offW1, offb1, offW2, offb2;        // element offsets of the four gradients inside a row
-  long chunk, step_index;                 // asynchronous variant only (see xa_push): floats per shard, global_step
+  long step_index;                        // asynchronous variant only (see xa_push): element of global_step
+  unsigned start[DTF_XGMI_MAX_RANKS];     // asynchronous variant only: first slab element of every shard
   int rank, world;
   long long timeout_ticks;
 };
@@ -610,13 +611,14 @@ __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, lo
 
 // Asynchronous variant (XW < 0): the same per-thread outputs are not swapped but PUSHED -- each gradient element is
 // applied where the variable lives, `shard_owner(e)[e] -= lr * g`, as one fire-and-forget float atomic through
-// the peer mapping (x.inbox[k] then holds the base of rank k's slab-sized shard buffer).  No worker waits for
+// the peer mapping.  Shard k holds the slab elements [start[k], start[k+1]) and x.inbox[k] is the address slab
+// element 0 WOULD have in rank k's buffer (the host subtracts the shard's offset), so equal shards of a flat slab
+// and whole variables dealt round-robin over parameter-server tasks are the same code.  No worker waits for
 // anything: the lock-free parameter-server update of the reference (tfdist_between.py:65-66) without a launch
 // of its own, and, being atomic, without lost updates.
 __device__ __forceinline__ void xa_push(const XgParams& x, long e, float delta) {
-  const unsigned owner = (unsigned)e / (unsigned)x.chunk;
   uint64_t* base = x.inbox[0];
-  for (int k = 1; k < x.world; ++k) base = (owner == (unsigned)k) ? x.inbox[k] : base;
+  for (int k = 1; k < x.world; ++k) base = ((unsigned)e >= x.start[k]) ? x.inbox[k] : base;
   (void)__hip_atomic_fetch_add(reinterpret_cast<float*>(base) + e, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1341,27 +1343,50 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
 }
 
 // Step of an asynchronous worker: forward, then a backward that pushes every gradient element into the shard
-// that owns it (x->inbox[k] = base of rank k's slab-sized shard buffer, x->n = floats per shard) and counts the
-// push in global_step (x->step_index, < 0: not counted).  Two launches; see xa_push.
+// that owns it and counts the push in global_step (x->step_index, < 0: not counted).  Two launches; see xa_push.
+// x->n > 0: `world` equal shards of n floats, x->inbox[k] = base of rank k's slab-sized buffer;
+// x->n == 0: shard k holds slab elements [shard_start[k], shard_start[k+1]) and x->inbox[k] is the address of ITS
+// first element (shards of different sizes, e.g. whole variables dealt over parameter-server tasks).
 extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream) {
   if (!d || !x) return DTF_ERR_NULL;
   if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
-  if (x->world < 1 || x->world > DTF_XGMI_MAX_RANKS || x->n <= 0 || (x->n & 3)) return DTF_ERR_SHAPE;
+  if (x->world < 1 || x->world > DTF_XGMI_MAX_RANKS || x->n < 0 || (x->n & 3)) return DTF_ERR_SHAPE;
   if (!d->gW1 || !d->gb1 || !d->gW2 || !d->gb2) return DTF_ERR_NULL;     // valid (unused) gradient locations
-  const long K = d->in_dim, H = d->hidden, C = d->classes, total = x->n * x->world;
-  if (total >= (1L << 32) || x->step_index >= total || x->offW1 < 0 || x->offW1 + K * H > total || x->offb1 < 0 ||
+  const long K = d->in_dim, H = d->hidden, C = d->classes;
+  XgParams a;
+  long total = 0;
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+    a.inbox[r] = nullptr;
+    a.start[r] = 0xffffffffu;
+  }
+  if (x->n > 0) {
+    total = x->n * x->world;
+    if (total >= (1L << 32)) return DTF_ERR_SHAPE;
+    for (int r = 0; r < x->world; ++r) {
+      if (!x->inbox[r]) return DTF_ERR_NULL;
+      a.inbox[r] = reinterpret_cast<uint64_t*>(x->inbox[r]);
+      a.start[r] = (unsigned)(x->n * r);
+    }
+  } else {
+    if (x->shard_start[0] != 0) return DTF_ERR_SHAPE;
+    total = x->shard_start[x->world];
+    if (total <= 0 || total >= (1L << 32)) return DTF_ERR_SHAPE;
+    for (int r = 0; r < x->world; ++r) {
+      const long lo = x->shard_start[r], hi = x->shard_start[r + 1];
+      if (lo < 0 || hi < lo || hi > total) return DTF_ERR_SHAPE;
+      if (hi > lo && !x->inbox[r]) return DTF_ERR_NULL;
+      // address that slab element 0 would have: only elements lo..hi-1 are ever formed from it
+      a.inbox[r] = reinterpret_cast<uint64_t*>(reinterpret_cast<float*>(x->inbox[r]) - lo);
+      a.start[r] = (unsigned)lo;
+    }
+  }
+  if (x->step_index >= total || x->offW1 < 0 || x->offW1 + K * H > total || x->offb1 < 0 ||
       x->offb1 + H > total || x->offW2 < 0 || x->offW2 + H * C > total || x->offb2 < 0 || x->offb2 + C > total)
     return DTF_ERR_SHAPE;
-  XgParams a;
-  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
-    a.inbox[r] = r < x->world ? reinterpret_cast<uint64_t*>(x->inbox[r]) : nullptr;
-    if (r < x->world && !a.inbox[r]) return DTF_ERR_NULL;
-  }
   a.state = nullptr;
   a.n = 0;
   a.slot_words = 0;
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
-  a.chunk = x->n;
   a.step_index = x->step_index;
   a.rank = x->rank;
   a.world = x->world;
@@ -1398,8 +1423,8 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   a.n = x->n;
   a.slot_words = x->n * (long)x->world;
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;
-  a.chunk = 0;
   a.step_index = -1;
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) a.start[r] = 0u;
   a.rank = x->rank;
   a.world = x->world;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock

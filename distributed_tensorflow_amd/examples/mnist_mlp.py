@@ -21,6 +21,7 @@ Two execution tiers produce those lines:
 """
 from __future__ import annotations
 
+import os
 import time
 from types import SimpleNamespace
 from typing import Optional
@@ -225,7 +226,11 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
 
             ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, flags.batch_size,
                                seed=1000 + flags.task_index)
-            trainer = PsResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)))
+            # DTF_FUSED_PUSH=1 / 0 forces the push into the backward launch / into a launch per shard;
+            # by default the worker measures both against the live shards and keeps the faster
+            forced = os.environ.get("DTF_FUSED_PUSH", "auto")
+            trainer = PsResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)),
+                                        fused_push="auto" if forced == "auto" else forced != "0")
             trainer.prepare(steps_hint=(ds.batches_per_epoch,))
             print(trainer.describe(), flush=True)
             result = run_resident_loop(trainer, mnist, flags, writer, begin_time)

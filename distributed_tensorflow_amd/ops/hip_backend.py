@@ -90,6 +90,7 @@ class DtfXgDesc(C.Structure):
         ("timeout_ms", C.c_int32),
         ("reserved", C.c_int32),
         ("step_index", C.c_int64),
+        ("shard_start", C.c_int64 * 17),
     ]
 
 

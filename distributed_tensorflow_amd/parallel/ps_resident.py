@@ -9,6 +9,10 @@ worker's training split in HBM and turns a step into GPU work only::
     push     p_k -= lr * g_k on every shard            (SGD kernel writing through the mapping,
                                                         global_step += 1 on its owner shard)
 
+(with GPU-resident shards and no lock the push is not a launch per shard but part of the backward launch: every
+backward thread adds ``-lr * g`` of its own gradient element to the shard that holds the variable with one float
+atomic through the mapping, ``dtf_mlp_step_async``)
+
 With ``transport="ipc"`` all of it is device work on the worker's stream, so chunks of steps are
 captured into hipGraphs and the host issues one call per chunk; the update stays the reference's
 lock-free asynchronous rule (use_locking=False, tfdist_between.py:65): several such workers —
@@ -34,7 +38,8 @@ from .replicas import _BaseTrainer
 class PsResidentTrainer(_BaseTrainer):
     name = "ps-resident"
 
-    def __init__(self, sess, train_op, dataset, batch: int, chunk: int = 50, use_graph: bool = True):
+    def __init__(self, sess, train_op, dataset, batch: int, chunk: int = 50, use_graph: bool = True,
+                 fused_push="auto"):
         plan = sess._plan(train_op)
         m = plan["mlp"]
         if m is None:
@@ -68,16 +73,84 @@ class PsResidentTrainer(_BaseTrainer):
             self.store.pull(self.params)
             self.engine.step_grad(0, 1.0)
             self.store.push_apply(self.grads, 0.0, False, bump_step=False)
+            if hasattr(self.store, "_lr"):
+                self.store._lr(self.lr_value)  # eagerly: a fill recorded into a graph runs only when THAT graph does
             torch.cuda.synchronize(self.device)
             self.engine.reset_step_workspace(0)
+        self._push_desc = None
+        self._dry = False              # calibration: pushes that add zero and are not counted
+        self.push_probe_us = None
+        if (fused_push and self.device.type == "cuda" and not self.use_locking
+                and hasattr(self.store, "push_descriptor")):
+            from ..ops import hip_backend as hb
+
+            offs = {r: self.layout.var_range[n][0] for r, n in names.items()}
+            try:
+                # load the pushing backward too, with lr = 0 and no count; shapes the two-launch step does not
+                # cover, or more shards than its table holds, keep the push kernels
+                self.engine.lr.zero_()
+                self.engine.step_async(0, self.store.push_descriptor(offs, bump_step=False))
+                self._push_desc = self.store.push_descriptor(offs, bump_step=self.bump_step)
+            except (ValueError, hb.HipKernelError):
+                self._push_desc = None
+            finally:
+                self.engine.lr.fill_(self.lr_value)
+                torch.cuda.synchronize(self.device)
+                self.engine.reset_step_workspace(0)
+            if self._push_desc is not None and fused_push == "auto" and self.use_graph:
+                self._choose_push(self.store.push_descriptor(offs, bump_step=False))
+
+    def _choose_push(self, dry_desc):
+        """Time both forms of the push against the live shards and keep the faster one.
+
+        One float atomic per gradient element travels as many small packets; a push kernel per shard moves whole
+        vectors but costs a launch per shard.  Which wins depends on how many shards there are, whether they sit
+        on this GPU or behind xGMI, and who else is pushing, so it is measured: a chunk of steps of each form is
+        captured with a learning rate of zero and no step count (the shards receive ``+ 0``), replayed, timed."""
+        real = self._push_desc
+        n = min(self.chunk, self.engine.batches_per_epoch)
+        times = {}
+        self._dry = True
+        self.engine.lr.zero_()
+        try:
+            for form, desc in (("fused", dry_desc), ("kernel", None)):
+                self._push_desc = desc
+                g = self._capture(0, n, 0)
+                start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    g.replay()
+                start.record()
+                for _ in range(8):
+                    g.replay()
+                stop.record()
+                stop.synchronize()
+                times[form] = 1000.0 * start.elapsed_time(stop) / (8 * n)
+                del g
+        except Exception:  # noqa: BLE001 — a runtime that cannot capture these steps: prepare() will find out as well
+            times = {}
+        finally:
+            self._dry = False
+            self.engine.lr.fill_(self.lr_value)
+            self.store._lr(self.lr_value)      # eagerly: a fill recorded into a graph runs only when THAT graph does
+            torch.cuda.synchronize(self.device)
+            self.engine.reset_step_workspace(0)
+        self.push_probe_us = {k: round(v, 2) for k, v in times.items()} or None
+        self._push_desc = real if (not times or times["fused"] <= times["kernel"]) else None
 
     def _one_step(self, batch_index: int):
         with span("pull"):
             self.store.pull(self.params)
+        if self._push_desc is not None:
+            with span("step_push_apply"):
+                self.engine.step_async(batch_index, self._push_desc)
+            return
         with span("step"):
             self.engine.step_grad(batch_index, 1.0)
         with span("push_apply"):
-            self.store.push_apply(self.grads, self.lr_value, self.use_locking, bump_step=self.bump_step)
+            if self._dry:
+                self.store.push_apply(self.grads, 0.0, False, bump_step=False)
+            else:
+                self.store.push_apply(self.grads, self.lr_value, self.use_locking, bump_step=self.bump_step)
 
     def _capture(self, pos: int, n: int, parity: int):
         # No warm-up replay here: a step writes the shared shards, which cannot be rolled back.
@@ -107,7 +180,11 @@ class PsResidentTrainer(_BaseTrainer):
         return self.store.global_step()
 
     def describe(self) -> str:
-        return (f"between-graph async worker, device-resident: pull -> 2 launches -> one-sided SGD push "
+        push = ("forward -> backward that pushes -lr*g per element into the owning shard (float atomics)"
+                if self._push_desc is not None else "2 launches -> one-sided SGD push")
+        if self.push_probe_us:
+            push += " [measured us/step: " + ", ".join(f"{k} {v}" for k, v in self.push_probe_us.items()) + "]"
+        return (f"between-graph async worker, device-resident: pull -> {push} "
                 f"({type(self.store).__name__}" + (", hipGraph chunks of %d)" % self.chunk if self.use_graph else ", eager)"))
 
 

@@ -112,9 +112,11 @@ def main(argv=None) -> int:
             out["ok2"] = False
             out["error2"] = f"{type(e).__name__}: {e}"
         print(json.dumps(out), flush=True)
-        # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes; first with
-        # the push inside the backward launch (float atomics through the mappings), then, should that not hold
-        # here (a push lost or not counted), with the push as a launch of its own
+        # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes, with the push
+        # inside the backward launch (one float atomic per element through the mappings: a launch less, many small
+        # packets) and with the push as a launch of its own (whole vectors); the faster form that kept every push
+        # is the one reported
+        forms = {}
         for fused_push in (True, False):
             ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
                                        rank=args.rank, world=args.world, chunk=args.chunk, use_graph=True,
@@ -135,15 +137,18 @@ def main(argv=None) -> int:
             a_fin = bool(torch.isfinite(ta.params).all())
             times = [None] * args.world
             dist.all_gather_object(times, (dta, a_fin and gs == 2 * args.steps * args.world and loss1 <= loss0))
-            out.update(async_ok=all(x[1] for x in times), async_global_step=gs, async_fused_push=fused_push,
-                       async_ms_per_step=round(1000.0 * max(x[0] for x in times) / args.steps, 5),
-                       async_loss=[round(loss0, 4), round(loss1, 4)])
-            note(f"async (push {'inside the backward' if fused_push else 'as a launch'}) ok={out['async_ok']} "
-                 f"{out['async_ms_per_step']} ms/step")
+            forms[fused_push] = dict(async_ok=all(x[1] for x in times), async_global_step=gs,
+                                     async_fused_push=fused_push,
+                                     async_ms_per_step=round(1000.0 * max(x[0] for x in times) / args.steps, 5),
+                                     async_loss=[round(loss0, 4), round(loss1, 4)])
+            note(f"async (push {'inside the backward' if fused_push else 'as a launch'}) "
+                 f"ok={forms[fused_push]['async_ok']} {forms[fused_push]['async_ms_per_step']} ms/step")
             dist.barrier()
             ta.close()
-            if out["async_ok"]:
-                break
+        good = [f for f in forms.values() if f["async_ok"]] or list(forms.values())
+        out.update(min(good, key=lambda f: f["async_ms_per_step"]))
+        out["async_ms_per_step_by_push"] = {("in_backward" if k else "own_launch"): v["async_ms_per_step"]
+                                            for k, v in forms.items()}
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer: "do not use this path here"
         out["error"] = f"{type(e).__name__}: {e}"

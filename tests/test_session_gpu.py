@@ -128,6 +128,7 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
     for i in range(n_w):
         out = res[f"worker{i}"][1]
         assert "hipGraph chunks" in out, out[-2000:]
+        assert "measured us/step: fused" in out, out[-2000:]     # both forms of the push were timed, one was kept
         assert out.rstrip().endswith("Done")
         finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
         costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
