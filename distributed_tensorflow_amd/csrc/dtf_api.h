@@ -143,6 +143,8 @@ int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad
 int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local, void* stream);
 int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const float* grad, const float* lr,
                       int64_t step_index, void* stream);
+// Shards of different sizes: shard k = slab elements [starts[k], starts[k+1]), shards[k] = address of its first element.
+int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int world, float* local, void* stream);
 
 const char* dtf_hip_build_info(void);
 

@@ -218,6 +218,25 @@ __global__ __launch_bounds__(kBlock) void shard_push_sgd_kernel(ShardArgs a, con
   }
 }
 
+// Shards of different sizes (whole variables dealt round-robin over parameter-server tasks): shard k holds the
+// slab vectors [startv[k], startv[k+1]) and base[k] is the address slab vector 0 WOULD have in its buffer (the
+// host subtracts the shard's offset), so the owner of a vector is found with comparisons and no division.
+struct RangeArgs {
+  const f32x4* base[kMaxRanks];
+  unsigned startv[kMaxRanks];
+  unsigned nvec;
+  int world;
+};
+
+__global__ __launch_bounds__(kBlock) void range_pull_kernel(RangeArgs a, f32x4* __restrict__ local) {
+  const unsigned stride = gridDim.x * kBlock;
+  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < a.nvec; i += stride) {
+    const f32x4* src = a.base[0];
+    for (int k = 1; k < a.world; ++k) src = (i >= a.startv[k]) ? a.base[k] : src;
+    local[i] = src[i];
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -368,6 +387,36 @@ extern "C" int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, f
   if (rc != DTF_OK) return rc;
   if (!local || !aligned16(local)) return DTF_ERR_NULL;
   hipLaunchKernelGGL(shard_pull_kernel, shard_grid(a.n), dim3(kBlock), 0, (hipStream_t)stream, a, local);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// local[0 .. starts[world]) = shard 0 ++ shard 1 ++ ...: shard k holds the slab elements [starts[k], starts[k+1])
+// and shards[k] is the device address of ITS first element (HOST arrays; empty shards may have address 0).
+// Ranges and addresses must be 16-byte aligned.  One launch whatever the number of shards.
+extern "C" int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int world, float* local,
+                                    void* stream) {
+  if (!shards || !starts) return DTF_ERR_NULL;
+  if (world < 1 || world > kMaxRanks || starts[0] != 0) return DTF_ERR_SHAPE;
+  if (!local || !aligned16(local)) return DTF_ERR_NULL;
+  const int64_t total = starts[world];
+  if (total <= 0 || (total & 3) || total >= (int64_t(1) << 33)) return DTF_ERR_SHAPE;
+  RangeArgs a;
+  for (int r = 0; r < kMaxRanks; ++r) {
+    a.base[r] = nullptr;
+    a.startv[r] = 0xffffffffu;
+  }
+  for (int r = 0; r < world; ++r) {
+    const int64_t lo = starts[r], hi = starts[r + 1];
+    if (lo < 0 || hi < lo || hi > total || (lo & 3)) return DTF_ERR_SHAPE;
+    const float* p = reinterpret_cast<const float*>(shards[r]);
+    if (hi > lo && (!p || !aligned16(p))) return DTF_ERR_NULL;
+    a.base[r] = reinterpret_cast<const f32x4*>(p - lo);      // only vectors lo/4 .. hi/4-1 are ever formed from it
+    a.startv[r] = (unsigned)(lo >> 2);
+  }
+  a.nvec = (unsigned)(total >> 2);
+  a.world = world;
+  hipLaunchKernelGGL(range_pull_kernel, shard_grid(total), dim3(kBlock), 0, (hipStream_t)stream, a,
+                     reinterpret_cast<f32x4*>(local));
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

@@ -35,6 +35,7 @@ tokens, locks) uses the native task servers.
 """
 from __future__ import annotations
 
+import ctypes as C
 import pickle
 import struct
 import time
@@ -203,10 +204,32 @@ class IpcVariableStore:
 
     # -- data plane --------------------------------------------------------------------------
     def pull(self, local: torch.Tensor, locked: bool = False):
+        """Every shard into the local slab: one launch reading all the mapped shards (a copy per shard when there
+        are more shards than the kernel's table holds)."""
+        tab = self._pull_table()
+        if tab is not None and local.is_contiguous() and local.numel() == tab[2]:
+            hb._check(hb.require().dtf_xgmi_pull_ranges(tab[0], tab[1], self.n, local.data_ptr(),
+                                                        torch.cuda.current_stream(self.device).cuda_stream),
+                      "dtf_xgmi_pull_ranges")
+            return
         for k in range(self.n):
             a, b = self.layout.shard_range[k]
             if b > a:
                 local[a:b].copy_(self._params(k), non_blocking=True)
+
+    def _pull_table(self):
+        """Host arrays for ``dtf_xgmi_pull_ranges``: first-element address and slab range of every shard."""
+        tab = getattr(self, "_pull_tab", False)
+        if tab is False:
+            tab = None
+            total = self.layout.shard_range[self.n - 1][1]
+            if self.n <= hb.require().dtf_xgmi_max_ranks() and total % 4 == 0:
+                ptrs = (C.c_uint64 * self.n)(*[self._params(k).data_ptr() if self.layout.shard_numel(k) else 0
+                                               for k in range(self.n)])
+                starts = (C.c_int64 * (self.n + 1))(*[self.layout.shard_range[k][0] for k in range(self.n)], total)
+                tab = (ptrs, starts, total)
+            self._pull_tab = tab
+        return tab
 
     def push_apply(self, grads: torch.Tensor, lr: float, use_locking: bool = False, bump_step: bool = True):
         lr_t = self._lr(lr)

@@ -117,3 +117,30 @@ def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_
         assert r["moved"] > 1e-3
         assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r
         assert "inside the backward launch" in r["describe"]
+
+
+@pytest.mark.gpu
+def test_one_launch_pull_over_shards_of_different_sizes():
+    """``dtf_xgmi_pull_ranges``: slab = shard 0 ++ shard 1 ++ ..., an empty shard in the middle included."""
+    import ctypes as C
+
+    import torch
+
+    from distributed_tensorflow_amd.ops import hip_backend as hb
+
+    dev = torch.device("cuda", 0)
+    sizes = [78404, 0, 1100, 12]
+    shards = [torch.randn(max(n, 4), device=dev)[:n] for n in sizes]
+    starts = [0]
+    for n in sizes:
+        starts.append(starts[-1] + n)
+    local = torch.zeros(starts[-1], device=dev)
+    ptrs = (C.c_uint64 * len(sizes))(*[t.data_ptr() if t.numel() else 0 for t in shards])
+    st = (C.c_int64 * len(starts))(*starts)
+    rc = hb.require().dtf_xgmi_pull_ranges(ptrs, st, len(sizes), local.data_ptr(),
+                                           torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(local, torch.cat(shards))
+    st_bad = (C.c_int64 * len(starts))(*[s + 2 if 0 < i < len(sizes) else s for i, s in enumerate(starts)])
+    assert hb.require().dtf_xgmi_pull_ranges(ptrs, st_bad, len(sizes), local.data_ptr(), None) != 0   # unaligned range
