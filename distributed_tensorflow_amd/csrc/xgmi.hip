@@ -184,16 +184,7 @@ __device__ __forceinline__ float* shard_of(const ShardArgs& a, int owner) {
   return p;
 }
 
-// (32-bit vector indices: the host checks that the slab has fewer than 2^31 vectors; a 64-bit division per
-// thread would cost more than the copy)
-__global__ __launch_bounds__(kBlock) void shard_pull_kernel(ShardArgs a, float* __restrict__ local) {
-  const unsigned nvec = (unsigned)(a.n >> 2), cvec = (unsigned)(a.chunk >> 2);
-  const unsigned stride = gridDim.x * kBlock;
-  f32x4* l4 = reinterpret_cast<f32x4*>(local);
-  for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride)
-    l4[i] = reinterpret_cast<const f32x4*>(shard_of(a, (int)(i / cvec)))[i];
-}
-
+// (32-bit vector indices: the host checks that the slab has fewer than 2^31 vectors)
 __global__ __launch_bounds__(kBlock) void shard_push_sgd_kernel(ShardArgs a, const float* __restrict__ grad,
                                                                 const float* __restrict__ lr_ptr, int64_t step_index) {
   const float lr = *lr_ptr;
@@ -379,6 +370,8 @@ static dim3 shard_grid(int64_t n) {
   return dim3((unsigned)blocks);
 }
 
+static int launch_range_pull(const RangeArgs& a, float* local, hipStream_t stream);
+
 // local[0 .. world*chunk) = the authoritative copy of every shard.  shards: HOST array of `world` device
 // addresses, entry k = base of rank k's slab-sized buffer (own entry local, the others mapped).
 extern "C" int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local, void* stream) {
@@ -386,7 +379,21 @@ extern "C" int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, f
   const int rc = fill_shards(a, shards, world, chunk);
   if (rc != DTF_OK) return rc;
   if (!local || !aligned16(local)) return DTF_ERR_NULL;
-  hipLaunchKernelGGL(shard_pull_kernel, shard_grid(a.n), dim3(kBlock), 0, (hipStream_t)stream, a, local);
+  RangeArgs r;
+  for (int k = 0; k < kMaxRanks; ++k) {
+    r.base[k] = k < world ? reinterpret_cast<const f32x4*>(a.shard[k]) : nullptr;   // slab-sized buffers: no offset
+    r.startv[k] = k < world ? (unsigned)((chunk >> 2) * k) : 0xffffffffu;
+  }
+  r.nvec = (unsigned)(a.n >> 2);
+  r.world = world;
+  return launch_range_pull(r, local, (hipStream_t)stream);
+}
+
+static int launch_range_pull(const RangeArgs& a, float* local, hipStream_t stream) {
+  // (blocks of 128 or 64 threads, i.e. more, smaller workgroups, measured no faster: 14.7 / 17.2 against 14.6 us/step)
+  unsigned blocks = (a.nvec + kBlock - 1) / kBlock;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(range_pull_kernel, dim3(blocks), dim3(kBlock), 0, stream, a, reinterpret_cast<f32x4*>(local));
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
@@ -415,9 +422,7 @@ extern "C" int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* start
   }
   a.nvec = (unsigned)(total >> 2);
   a.world = world;
-  hipLaunchKernelGGL(range_pull_kernel, shard_grid(total), dim3(kBlock), 0, (hipStream_t)stream, a,
-                     reinterpret_cast<f32x4*>(local));
-  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+  return launch_range_pull(a, local, (hipStream_t)stream);
 }
 
 // Every shard -= lr * (its range of grad), written through the mappings; step_index >= 0: the element
