@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5500)
     ap.add_argument("--warmup", type=int, default=550)
-    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "xgmi", "xgmi2", "xgmi_async", "auto"],
+    ap.add_argument("--mode", default=None, choices=[None, "single", "sync", "async", "towers", "xgmi", "xgmi2", "xgmi2c", "xgmi_async", "auto"],
                     help="N=1 default: single; N>1 default: auto = the fastest of sync (PS shard per GPU, RCCL "
                          "reduce-scatter/all-gather), towers (RCCL all-reduce, replicated apply), xgmi (one exchange "
                          "kernel over peer-mapped HBM) and xgmi2 (exchange inside the backward launch), probed before "

@@ -13,6 +13,7 @@ BASELINE_MULTI = 3 * 55000.0 / 6.03
 BATCH = 100
 STEPS_PER_EPOCH = 550
 LR = 0.001
+PEER_MODES = ("xgmi", "xgmi2", "xgmi2c")      # synchronous exchanges over peer-mapped HBM (parallel/xgmi.py)
 
 
 def _dist_env():
@@ -117,12 +118,12 @@ def run_benchmark(args) -> Optional[dict]:
     if distributed:
         lib_backend = not (use_cpu or share_gpu)
         dist.init_process_group(backend="nccl" if lib_backend else "gloo", device_id=device if lib_backend else None)
-    xgmi_ok = xgmi2_ok = peer_async_ok = False
+    xgmi_ok = xgmi2_ok = xgmi2c_ok = peer_async_ok = False
     if trial is not None:
-        flag = torch.tensor([1 if trial.get(k) else 0 for k in ("ok", "async_ok", "ok2")], dtype=torch.int32,
+        flag = torch.tensor([1 if trial.get(k) else 0 for k in ("ok", "async_ok", "ok2", "ok2c")], dtype=torch.int32,
                             device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        xgmi_ok, peer_async_ok, xgmi2_ok = (bool(int(v)) for v in flag.tolist())
+        xgmi_ok, peer_async_ok, xgmi2_ok, xgmi2c_ok = (bool(int(v)) for v in flag.tolist())
         if rank == 0 and not xgmi_ok:
             print(f"[bench] peer-mapped exchange not used on this node: {trial}", file=sys.stderr, flush=True)
 
@@ -134,7 +135,7 @@ def run_benchmark(args) -> Optional[dict]:
 
     def build(m):
         # gloo collectives (the one-GPU rehearsal) cannot be captured; the peer-mapped exchange can
-        graph = not args.no_graph and not (share_gpu and m not in ("xgmi", "xgmi2", "xgmi_async"))
+        graph = not args.no_graph and not (share_gpu and m not in PEER_MODES + ("xgmi_async",))
         extra = {"uncached_grads": bool(trial and trial.get("uncached_grads"))} if m == "xgmi" else {}
         return build_replica_trainer(mode=m, device=device, dataset=ds, batch=BATCH, lr=LR, seed=1,
                                      rank=rank, world=world, chunk=int(args.chunk), use_graph=graph, **extra)
@@ -180,7 +181,8 @@ def run_benchmark(args) -> Optional[dict]:
         probe_ms, best = {}, None
         # (the one-GPU rehearsal keeps its gloo group out of the per-step path whenever it can)
         library = ("sync", "towers") if not share_gpu else (() if xgmi_ok else ("towers",))
-        for cand in (("xgmi2",) if xgmi2_ok else ()) + (("xgmi",) if xgmi_ok else ()) + library:
+        for cand in ((("xgmi2c",) if xgmi2c_ok else ()) + (("xgmi2",) if xgmi2_ok else ())
+                     + (("xgmi",) if xgmi_ok else ()) + library):
             if rank == 0:
                 print(f"[bench] probing {cand}", file=sys.stderr, flush=True)
             try:
@@ -210,10 +212,10 @@ def run_benchmark(args) -> Optional[dict]:
         if best is None:
             raise SystemExit("no data-parallel mode could run on this node")
         mode, trainer = best
-        if mode not in ("xgmi", "xgmi2"):
+        if mode not in PEER_MODES:
             fallback_mode = None
         else:       # should the peer-mapped run turn out inconsistent: the fastest library mode
-            fallback_mode = min((m for m in probe_ms if m not in ("xgmi", "xgmi2") and probe_ms[m] is not None),
+            fallback_mode = min((m for m in probe_ms if m not in PEER_MODES and probe_ms[m] is not None),
                                 key=lambda m: probe_ms[m], default=None)
     else:
         trainer = build(mode)
@@ -230,7 +232,7 @@ def run_benchmark(args) -> Optional[dict]:
         return time.perf_counter() - t0
 
     elapsed = timed(trainer)
-    if mode in ("xgmi", "xgmi2"):
+    if mode in PEER_MODES:
         # The replicas sum in rank order, so they must be bit-identical; anything else (or an exchange that
         # timed out) voids the measurement and the run is repeated with the library collectives.
         good = torch.tensor([1 if trainer.healthy() else 0, trainer.replica_checksum()], dtype=torch.int64,
@@ -351,8 +353,8 @@ def run_benchmark(args) -> Optional[dict]:
             result["async_mode"] = async_report
         if trial is not None:
             result["peer_exchange_trial"] = {k: trial.get(k) for k in ("ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok", "async_fused_push", "async_ms_per_step_by_push",
-                                                       "async_ms_per_step", "async_loss", "ok2", "ms_per_step2",
-                                                       "error", "error2")
+                                                       "async_ms_per_step", "async_loss", "ok2", "ms_per_step2", "ok2c", "ms_per_step2c",
+                                                       "error", "error2", "error2c")
                                              if k in trial}
     if hasattr(trainer, "close"):
         _sync(device, distributed)

@@ -127,7 +127,9 @@ typedef struct DtfXgDesc {
   uint32_t* state;                      // 4 zero-initialised words in local memory
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
-  int32_t rank, world, timeout_ms, reserved;
+  int32_t rank, world, timeout_ms;
+  int32_t compact;                      // dtf_mlp_step_xg: inbox words are bare 4-byte values, unwritten ones hold
+                                        // 0xffffffff (the inbox must be filled with that pattern beforehand)
   int64_t step_index;                   // dtf_mlp_step_async only: element that holds global_step (< 0: none)
   int64_t shard_start[DTF_XGMI_MAX_RANKS + 1];   // dtf_mlp_step_async with n == 0: slab range of every shard
 } DtfXgDesc;
@@ -144,6 +146,8 @@ int dtf_xgmi_pull(const uint64_t* shards, int world, int64_t chunk, float* local
 int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const float* grad, const float* lr,
                       int64_t step_index, void* stream);
 // Shards of different sizes: shard k = slab elements [starts[k], starts[k+1]), shards[k] = address of its first element.
+// Fills `bytes` bytes at p with `byte` and waits for it (initial pattern of a compact inbox).
+int dtf_xgmi_fill(void* p, int byte, int64_t bytes);
 int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int world, float* local, void* stream);
 
 const char* dtf_hip_build_info(void);

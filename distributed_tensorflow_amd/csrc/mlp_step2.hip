@@ -563,14 +563,69 @@ struct XgParams {
   long step_index;                        // asynchronous variant only (see xa_push): element of global_step
   unsigned start[DTF_XGMI_MAX_RANKS];     // asynchronous variant only: first slab element of every shard
   int rank, world;
+  int compact;                            // 4-byte words with a "not yet written" pattern (see xg_exchange_compact)
   long long timeout_ticks;
 };
+
+// The same exchange with HALF the bytes on the links: values travel as bare 4-byte floats and an inbox word that
+// has not been written yet holds kXgEmpty, a NaN pattern no computation produces (hardware NaNs are 0x7fc00000 or
+// an operand's payload; a value that does carry the pattern is sent as the canonical NaN).  The reader puts the
+// pattern back into its own inbox words as soon as it has consumed them.  That store is over when the launch is
+// over, the launch is over before this replica sends its values of exchange s+1, and a peer needs those to get
+// through exchange s+1 at all -- so the pattern is in place long before the peer's values of exchange s+2, the
+// next ones aimed at the same slot, can arrive.  A link carries 4 bytes per gradient element and step.
+constexpr uint32_t kXgEmpty = 0xffffffffu;
+
+template <int W>
+__device__ __forceinline__ float xg_exchange_compact(const XgParams& x, unsigned seq, long e, float own, int* failed) {
+  uint32_t bits = __float_as_uint(own);
+  bits = bits == kXgEmpty ? 0x7fc00000u : bits;
+  const long slot = (seq & 1u) ? x.slot_words : 0L;
+#pragma unroll
+  for (int r = 0; r < W; ++r)
+    if (r < x.world && r != x.rank)
+      __hip_atomic_store(reinterpret_cast<uint32_t*>(x.inbox[r]) + slot + (long)x.rank * x.n + e, bits,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint32_t* mine = reinterpret_cast<uint32_t*>(x.inbox[x.rank]) + slot + e;
+  uint32_t v[W];
+  long long t0 = 0;
+#pragma unroll 1
+  for (unsigned spin = 1;; ++spin) {
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      if (r < x.world && r != x.rank) {
+        v[r] = __hip_atomic_load(mine + (long)r * x.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = all && v[r] != kXgEmpty;
+      }
+    }
+    if (all) break;
+    if ((spin & 63u) == 0u) {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > x.timeout_ticks) {
+        *failed = 1;
+        return own;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int r = 0; r < W; ++r) {
+    if (r < x.world && r != x.rank)
+      __hip_atomic_store(mine + (long)r * x.n, kXgEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (r < x.world) total += (r == x.rank) ? __uint_as_float(bits) : __uint_as_float(v[r]);
+  }
+  return total;
+}
 
 // Publishes `own` as element e of exchange `seq` and returns the rank-ordered sum over all replicas.
 // W: compile-time bound on the replica count (keeps the code small and every peer's load in flight at once).
 // *failed is raised (and the caller must not apply the result) when a peer's value never arrives.
-template <int W>
+template <int W, bool COMPACT = false>
 __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, long e, float own, int* failed) {
+  if constexpr (COMPACT) return xg_exchange_compact<W>(x, seq, e, own, failed);
   const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
   const long slot = (seq & 1u) ? x.slot_words : 0L;
 #pragma unroll
@@ -617,12 +672,15 @@ __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, lo
 // anything: the lock-free parameter-server update of the reference (tfdist_between.py:65-66) without a launch
 // of its own, and, being atomic, without lost updates.
 __device__ __forceinline__ void xa_push(const XgParams& x, long e, float delta) {
+  // (fully unrolled over the table: entries past the last shard start at 0xffffffff and never match; a loop
+  // bounded by x.world makes the compiler copy the table into scratch memory, which costs every launch ~1 us)
   uint64_t* base = x.inbox[0];
-  for (int k = 1; k < x.world; ++k) base = ((unsigned)e >= x.start[k]) ? x.inbox[k] : base;
+#pragma unroll
+  for (int k = 1; k < DTF_XGMI_MAX_RANKS; ++k) base = ((unsigned)e >= x.start[k]) ? x.inbox[k] : base;
   (void)__hip_atomic_fetch_add(reinterpret_cast<float*>(base) + e, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int NS, int CQ, int NA, bool YV2, int XW = 0>
+template <int NS, int CQ, int NA, bool YV2, int XW = 0, bool XC = false>
 __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin,
                                                 const XgParams* xg = nullptr) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
@@ -926,9 +984,8 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   }
   if constexpr (XW < 0) {
     const XgParams& x = *xg;
-#pragma unroll 1
-    for (int item = 0; item < 2; ++item)
-      if (xv[item]) xa_push(x, xe[item], -lr * xown[item]);
+    if (xv[0]) xa_push(x, xe[0], -lr * xown[0]);
+    if (xv[1]) xa_push(x, xe[1], -lr * xown[1]);
     if (stats_block && tid == 0 && x.step_index >= 0) xa_push(x, x.step_index, 1.0f);
   }
   if constexpr (XW > 0) {
@@ -938,9 +995,11 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
       int lost = 0;
 #pragma unroll 1
       for (int item = 0; item < 2; ++item) {
-        if (!xv[item]) continue;
-        const float total = xg_exchange<XW>(x, seq, xe[item], xown[item], &lost);
-        if (!lost) *xdst[item] = xold[item] - lr * total;
+        // (selected with constant indices: indexing the arrays with `item` would put them into scratch memory,
+        // and a kernel that uses scratch at all starts ~1 us later)
+        if (!(item ? xv[1] : xv[0])) continue;
+        const float total = xg_exchange<XW, XC>(x, seq, item ? xe[1] : xe[0], item ? xown[1] : xown[0], &lost);
+        if (!lost) *(item ? xdst[1] : xdst[0]) = (item ? xold[1] : xold[0]) - lr * total;
       }
       if (lost) atomicExch(&x.state[2], 1u);
     }
@@ -955,10 +1014,10 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   bwd_tile16_body<NS, CQ, 2, YV2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-template <int NS, int CQ, bool YV2, int XW>
+template <int NS, int CQ, bool YV2, int XW, bool XC = false>
 __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_xg_kernel(BwdParams p, XgParams x) {
   __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
-  bwd_tile16_body<NS, CQ, 2, YV2, XW>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
+  bwd_tile16_body<NS, CQ, 2, YV2, XW, XC>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1323,16 +1382,21 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
   const bool yv2 = (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;
   if (xg) {
     const bool fast = cq <= 3 && yv2;
-#define DTF_XG_LAUNCH(W)                                                                            \
-  do {                                                                                              \
-    if (fast) hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true, W>), grid, block, 0, stream, p, *xg);  \
-    else hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false, W>), grid, block, 0, stream, p, *xg);      \
+#define DTF_XG_LAUNCH(W, XC)                                                                            \
+  do {                                                                                                  \
+    if (fast) hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true, W, XC>), grid, block, 0, stream, p, *xg);  \
+    else hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false, W, XC>), grid, block, 0, stream, p, *xg);      \
   } while (0)
-    if (xg_async) DTF_XG_LAUNCH(-1);
-    else if (xg->world <= 2) DTF_XG_LAUNCH(2);
-    else if (xg->world <= 4) DTF_XG_LAUNCH(4);
-    else if (xg->world <= 8) DTF_XG_LAUNCH(8);
-    else DTF_XG_LAUNCH(16);
+    if (xg_async) DTF_XG_LAUNCH(-1, false);
+    else if (xg->compact) {
+      if (xg->world <= 2) DTF_XG_LAUNCH(2, true);
+      else if (xg->world <= 4) DTF_XG_LAUNCH(4, true);
+      else if (xg->world <= 8) DTF_XG_LAUNCH(8, true);
+      else DTF_XG_LAUNCH(16, true);
+    } else if (xg->world <= 2) DTF_XG_LAUNCH(2, false);
+    else if (xg->world <= 4) DTF_XG_LAUNCH(4, false);
+    else if (xg->world <= 8) DTF_XG_LAUNCH(8, false);
+    else DTF_XG_LAUNCH(16, false);
 #undef DTF_XG_LAUNCH
   } else if (cq <= 3 && yv2) {
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
@@ -1390,6 +1454,7 @@ extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int pari
   a.step_index = x->step_index;
   a.rank = x->rank;
   a.world = x->world;
+  a.compact = 0;
   a.timeout_ticks = 0;
   return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true);
 }
@@ -1427,6 +1492,7 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) a.start[r] = 0u;
   a.rank = x->rank;
   a.world = x->world;
+  a.compact = x->compact != 0;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock
   return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a);
 }

@@ -273,6 +273,15 @@ extern "C" int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached) {
   return DTF_OK;
 }
 
+extern "C" int dtf_xgmi_fill(void* p, int byte, int64_t bytes) {
+  if (!p || bytes <= 0) return DTF_ERR_NULL;
+  if (hipMemset(p, byte, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    return DTF_ERR_LAUNCH;
+  }
+  return DTF_OK;
+}
+
 extern "C" int dtf_xgmi_free(void* p) {
   if (!p) return DTF_OK;
   return hipFree(p) == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;

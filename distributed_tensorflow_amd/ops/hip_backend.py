@@ -88,7 +88,7 @@ class DtfXgDesc(C.Structure):
         ("rank", C.c_int32),
         ("world", C.c_int32),
         ("timeout_ms", C.c_int32),
-        ("reserved", C.c_int32),
+        ("compact", C.c_int32),
         ("step_index", C.c_int64),
         ("shard_start", C.c_int64 * 17),
     ]
@@ -125,7 +125,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_pull.argtypes = [vp, i32, i64, vp, vp]
     lib.dtf_xgmi_push_sgd.argtypes = [vp, i32, i64, vp, vp, i64, vp]
     lib.dtf_xgmi_pull_ranges.argtypes = [vp, vp, i32, vp, vp]
-    for name in ("dtf_xgmi_pull", "dtf_xgmi_push_sgd", "dtf_xgmi_pull_ranges", "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
+    lib.dtf_xgmi_fill.argtypes = [vp, i32, i64]
+    for name in ("dtf_xgmi_pull", "dtf_xgmi_push_sgd", "dtf_xgmi_pull_ranges", "dtf_xgmi_fill",
+                 "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
                  "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_debug_force_generic_path.argtypes = [i32]

@@ -409,7 +409,7 @@ class XgmiFusedTrainer(_BaseTrainer):
 
     name = "xgmi2"
 
-    def __init__(self, *a, group=None, timeout_ms: int = 20000, **kw):
+    def __init__(self, *a, group=None, timeout_ms: int = 20000, compact: bool = False, **kw):
         kw["need_grads"] = False
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
@@ -418,8 +418,10 @@ class XgmiFusedTrainer(_BaseTrainer):
 
         self.engine.global_step = self.global_step
         self.engine._desc = None
+        self.compact = bool(compact)
+        self.name = "xgmi2c" if self.compact else "xgmi2"
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
-                            timeout_ms=timeout_ms)
+                            timeout_ms=timeout_ms, compact=self.compact)
         offs = {role: self.layout.var_range[name][0] for role, name in
                 (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
                  ("b2", "biases/Variable_1"))}
@@ -434,7 +436,9 @@ class XgmiFusedTrainer(_BaseTrainer):
     close = XgmiTowerTrainer.close
 
     def describe(self):
-        return (f"sync towers dp{self.world}: gradient exchange inside the backward launch ({{number, value}} words "
+        words = ("bare 4-byte values, unwritten words marked by a reserved NaN pattern," if self.compact
+                 else "{number, value} words")
+        return (f"sync towers dp{self.world}: gradient exchange inside the backward launch ({words} "
                 f"stored into the peers' inboxes over peer-mapped HBM, rank-ordered sum, in-place SGD), "
                 f"2 launches/step" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
@@ -540,7 +544,10 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi_async": XgmiAsyncTrainer}[mode]
+           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi2c": XgmiFusedTrainer,
+           "xgmi_async": XgmiAsyncTrainer}[mode]
+    if mode == "xgmi2c":        # the exchange inside the backward launch with 4-byte words
+        kw["compact"] = True
     if mode == "single" and kw.get("world", 1) != 1:
         raise ValueError("single mode is one process")
     return cls(**kw)

@@ -340,18 +340,23 @@ class PeerInbox:
     upper half of a word is the arrival flag of its lower half.
     """
 
-    def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None, timeout_ms: int = 5000):
+    def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None, timeout_ms: int = 5000,
+                 compact: bool = False):
         lib = hb.require()
         if not 1 <= world <= lib.dtf_xgmi_max_ranks():
             raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
         self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
         self.numel = int(numel)
         self.timeout_ms = int(timeout_ms)
-        self.slot_bytes = self.world * self.numel * 8
+        # compact: bare 4-byte values, a word nobody has written yet holds 0xffffffff (half the bytes on a link)
+        self.compact = bool(compact)
+        self.slot_bytes = self.world * self.numel * (4 if self.compact else 8)
         self._closed = False
         self._mapped: List[int] = []
         with torch.cuda.device(self.device):
             self._ptr = _alloc(2 * self.slot_bytes, True)
+            if self.compact:
+                hb._check(lib.dtf_xgmi_fill(self._ptr, 0xFF, 2 * self.slot_bytes), "dtf_xgmi_fill")
             # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and an
             # empty inbox, all zeros, never matches), [2]: error
             self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -359,7 +364,7 @@ class PeerInbox:
         self._ptrs[self.rank] = self._ptr
         if self.world > 1:
             everyone = _all_gather(group, {"rank": self.rank, "handle": _export(self._ptr),
-                                           "bytes": self.slot_bytes}, self.world)
+                                           "bytes": self.slot_bytes}, self.world)   # (differs if `compact` does)
             with torch.cuda.device(self.device):
                 for h in everyone:
                     if h["rank"] == self.rank:
@@ -380,6 +385,7 @@ class PeerInbox:
         d.n = self.numel
         d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
         d.rank, d.world, d.timeout_ms = self.rank, self.world, self.timeout_ms
+        d.compact = int(self.compact)
         return d
 
     def failed(self) -> bool:

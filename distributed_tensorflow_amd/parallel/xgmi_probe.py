@@ -84,34 +84,37 @@ def main(argv=None) -> int:
         print(json.dumps(out), flush=True)        # the caller reads the LAST line: later stages only add to it
         dist.barrier()
         t.close()
-        # the exchange inside the backward launch (2 launches per step), judged by the same criteria
-        try:
-            t2 = build_replica_trainer("xgmi2", device=dev, dataset=ds, batch=100, lr=0.001, seed=1, rank=args.rank,
-                                       world=args.world, chunk=args.chunk, use_graph=True, timeout_ms=10000)
-            q0 = t2.params.clone()
-            t2.prepare((args.steps, args.steps))
-            dist.barrier()
-            t2.run_steps(args.steps)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            t0 = time.perf_counter()
-            t2.run_steps(args.steps)
-            torch.cuda.synchronize(dev)
-            dt2 = time.perf_counter() - t0
-            sums2 = [None] * args.world
-            dist.all_gather_object(sums2, (t2.replica_checksum(), t2.healthy(), dt2,
-                                           bool(torch.isfinite(t2.params).all()),
-                                           float((t2.params - q0)[4:].abs().max()) > 0.0,
-                                           t2.global_step_value() == 2 * args.steps))
-            out.update(ok2=bool(all(s[1] and s[3] and s[4] and s[5] for s in sums2) and len({s[0] for s in sums2}) == 1),
-                       ms_per_step2=round(1000.0 * max(s[2] for s in sums2) / args.steps, 5))
-            note(f"in-backward exchange ok={out['ok2']} {out['ms_per_step2']} ms/step")
-            dist.barrier()
-            t2.close()
-        except Exception as e:  # noqa: BLE001 — collective calls above keep the ranks in step even when one fails here
-            out["ok2"] = False
-            out["error2"] = f"{type(e).__name__}: {e}"
-        print(json.dumps(out), flush=True)
+        # the exchange inside the backward launch (2 launches per step), with 8-byte {number, value} words and with
+        # bare 4-byte values (half the bytes on a link), each judged by the same criteria
+        for mode2, tag in (("xgmi2", "2"), ("xgmi2c", "2c")):
+            try:
+                t2 = build_replica_trainer(mode2, device=dev, dataset=ds, batch=100, lr=0.001, seed=1, rank=args.rank,
+                                           world=args.world, chunk=args.chunk, use_graph=True, timeout_ms=10000)
+                q0 = t2.params.clone()
+                t2.prepare((args.steps, args.steps))
+                dist.barrier()
+                t2.run_steps(args.steps)
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                t0 = time.perf_counter()
+                t2.run_steps(args.steps)
+                torch.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t0
+                sums2 = [None] * args.world
+                dist.all_gather_object(sums2, (t2.replica_checksum(), t2.healthy(), dt2,
+                                               bool(torch.isfinite(t2.params).all()),
+                                               float((t2.params - q0)[4:].abs().max()) > 0.0,
+                                               t2.global_step_value() == 2 * args.steps))
+                out["ok" + tag] = bool(all(s[1] and s[3] and s[4] and s[5] for s in sums2)
+                                       and len({s[0] for s in sums2}) == 1)
+                out["ms_per_step" + tag] = round(1000.0 * max(s[2] for s in sums2) / args.steps, 5)
+                note(f"in-backward exchange ({mode2}) ok={out['ok' + tag]} {out['ms_per_step' + tag]} ms/step")
+                dist.barrier()
+                t2.close()
+            except Exception as e:  # noqa: BLE001 — collective calls above keep the ranks in step even when one fails here
+                out["ok" + tag] = False
+                out["error" + tag] = f"{type(e).__name__}: {e}"
+            print(json.dumps(out), flush=True)
         # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes, with the push
         # inside the backward launch (one float atomic per element through the mappings: a launch less, many small
         # packets) and with the push as a launch of its own (whole vectors); the faster form that kept every push

@@ -1,6 +1,6 @@
 """One replica of the peer-mapped exchange test (several of these share the GPU).
 
-usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|async|async_sep]
+usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|sync2c|async|async_sep]
 Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference
 (sync), or the state of the shared shards after every worker finished (async).
 """
@@ -56,9 +56,9 @@ def main():
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
     if mode in ("async", "async_sep"):
         return run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=mode == "async")
-    t = build_replica_trainer("xgmi2" if mode == "sync2" else "xgmi", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
+    t = build_replica_trainer({"sync2": "xgmi2", "sync2c": "xgmi2c"}.get(mode, "xgmi"), device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
                               chunk=3, use_graph=bool(use_graph), timeout_ms=30000,
-                              **({} if mode == "sync2" else {"uncached_grads": bool(uncached)}))
+                              **({} if mode in ("sync2", "sync2c") else {"uncached_grads": bool(uncached)}))
     p0 = t.params.clone().cpu()
     t.prepare((steps,))
     dist.barrier()

@@ -104,13 +104,16 @@ def test_one_async_worker_trains_the_same_with_either_push():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,use_graph", [(1, True), (2, False), (2, True), (3, True)])
-def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_graph):
-    """Two launches per step: every backward thread swaps its element with the same thread of the peers.
+@pytest.mark.parametrize("world,use_graph,mode", [(1, True, "sync2"), (2, False, "sync2"), (2, True, "sync2"),
+                                                  (3, True, "sync2"), (1, True, "sync2c"), (2, False, "sync2c"),
+                                                  (2, True, "sync2c"), (3, True, "sync2c")])
+def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_graph, mode):
+    """Two launches per step: every backward thread swaps its element with the same thread of the peers
+    (``sync2``: 8-byte {number, value} words; ``sync2c``: bare 4-byte values and a "not yet written" pattern).
     (More than three replica processes do not fit on ONE GPU together: their spinning workgroups would wait for
     workgroups of a peer that cannot become resident.  One process per GPU has no such limit.)"""
     steps = 7
-    for r in _run_replicas(world, steps, use_graph, uncached=1, mode="sync2"):
+    for r in _run_replicas(world, steps, use_graph, uncached=1, mode=mode):
         assert r["healthy"], r
         assert r["identical"] and r["same_sum"], r
         assert r["global_step"] == steps
