@@ -239,8 +239,12 @@ class PsSyncResidentTrainer(_BaseTrainer):
         self.steps_done = 0
         self._graphs = {}
         group = StoreGroup(sess.server.client("ps", 0), "sync-resident", self.rank, self.world)
+        # DTF_XG_COMPACT=1: bare 4-byte words (half the bytes on a link; every worker must agree, the inbox sizes
+        # are compared when the handles are exchanged)
+        import os
+
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
-                            timeout_ms=timeout_ms)
+                            timeout_ms=timeout_ms, compact=os.environ.get("DTF_XG_COMPACT", "0") == "1")
         self._xg_desc = self.xg.step_descriptor({r: self.layout.var_range[n][0] for r, n in names.items()})
 
     def _one_step(self, batch_index: int):
