@@ -28,6 +28,8 @@ the mean of N gradients applied once per step, bit-identical replicas, two launc
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..models.mlp import MLPEngine
@@ -241,8 +243,6 @@ class PsSyncResidentTrainer(_BaseTrainer):
         group = StoreGroup(sess.server.client("ps", 0), "sync-resident", self.rank, self.world)
         # DTF_XG_COMPACT=1: bare 4-byte words (half the bytes on a link; every worker must agree, the inbox sizes
         # are compared when the handles are exchanged)
-        import os
-
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
                             timeout_ms=timeout_ms, compact=os.environ.get("DTF_XG_COMPACT", "0") == "1")
         self._xg_desc = self.xg.step_descriptor({r: self.layout.var_range[n][0] for r, n in names.items()})
