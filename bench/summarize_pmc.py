@@ -10,7 +10,10 @@ for f in files:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         short = "step_pipe" if "step_pipe" in name else "fwd_tile8" if "fwd_tile8" in name else \
-            "bwd_tile16" if "bwd_tile16" in name else "gather_rows" if "gather_rows" in name else None
+            "bwd_push" if ("bwd_tile16_xg" in name and "-1" in name) else \
+            "bwd_tile16_xg" if "bwd_tile16_xg" in name else \
+            "bwd_tile16" if "bwd_tile16" in name else "gather_rows" if "gather_rows" in name else \
+            "range_pull" if "range_pull" in name else "shard_push" if "shard_push" in name else None
         if short is None:
             continue
         k = (short, r["Counter_Name"])
