@@ -105,8 +105,8 @@ class PsResidentTrainer(_BaseTrainer):
     def _choose_push(self, dry_desc):
         """Time both forms of the push against the live shards and keep the faster one.
 
-        One float atomic per gradient element travels as many small packets; a push kernel per shard moves whole
-        vectors but costs a launch per shard.  Which wins depends on how many shards there are, whether they sit
+        The atomics of the pushing backward travel as 64-byte requests (the 16 lanes of a tile row) and contend
+        when several workers hit one shard; a push kernel per shard moves whole vectors but costs a launch per shard.  Which wins depends on how many shards there are, whether they sit
         on this GPU or behind xGMI, and who else is pushing, so it is measured: a chunk of steps of each form is
         captured with a learning rate of zero and no step count (the shards receive ``+ 0``), replayed, timed."""
         real = self._push_desc
