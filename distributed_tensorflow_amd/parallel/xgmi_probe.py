@@ -116,8 +116,8 @@ def main(argv=None) -> int:
                 out["error" + tag] = f"{type(e).__name__}: {e}"
             print(json.dumps(out), flush=True)
         # the asynchronous mode over the same kind of mappings: one-sided pulls and lock-free pushes, with the push
-        # inside the backward launch (one float atomic per element through the mappings: a launch less, many small
-        # packets) and with the push as a launch of its own (whole vectors); the faster form that kept every push
+        # inside the backward launch (one float atomic per element through the mappings: a launch less, 64-byte
+        # requests) and with the push as a launch of its own (whole vectors); the faster form that kept every push
         # is the one reported
         forms = {}
         for fused_push in (True, False):
