@@ -234,7 +234,8 @@ class PeerShards:
     Nothing here waits for another worker.
     """
 
-    def __init__(self, rank: int, world: int, chunk: int, device: torch.device, group=None):
+    def __init__(self, rank: int, world: int, chunk: int, device: torch.device, group=None,
+                 uncached: Optional[bool] = None):
         lib = hb.require()
         if not 1 <= world <= lib.dtf_xgmi_max_ranks():
             raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
@@ -244,8 +245,18 @@ class PeerShards:
         self.total = self.chunk * self.world
         self._closed = False
         self._mapped: List[int] = []
+        # A shard is updated by atomics of its own GPU (executed in that GPU's L2, which keeps the line) AND by
+        # atomics arriving over xGMI (executed at the memory): ordinary device memory is only made coherent between
+        # the two at kernel boundaries, so updates could overwrite each other.  The shards are therefore allocated
+        # uncached (fine-grained: every access goes to memory), which measured no slower than cached shards with
+        # all workers on one GPU (13.6 against 14.6 us/step; DTF_SHARDS_UNCACHED=0 brings the cached ones back).
+        if uncached is None:
+            import os
+
+            uncached = os.environ.get("DTF_SHARDS_UNCACHED", "1") != "0"
+        self.uncached = bool(uncached)
         with torch.cuda.device(self.device):
-            self._ptr = _alloc(self.total * 4, False)
+            self._ptr = _alloc(self.total * 4, self.uncached)
             self._buf = _DeviceBuffer(self._ptr, self.total * 4, "<f4", 4, True)
             self.buffer = torch.as_tensor(self._buf, device=self.device)
         ptrs = [0] * self.world
