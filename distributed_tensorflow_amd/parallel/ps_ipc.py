@@ -54,15 +54,28 @@ ACC_STEP = "__ipc_acc_step__"
 LOCK_Q = "__ipc_lock__"
 
 
-def _export(t: torch.Tensor) -> bytes:
-    from torch.multiprocessing.reductions import reduce_tensor
+def _allocate_shard(rows: int, cols: int, dev: torch.device) -> bytes:
+    """``rows x cols`` zeroed floats in UNCACHED memory of ``dev``; returns the blob the workers map it from.
 
-    return pickle.dumps(reduce_tensor(t))
+    A shard is written by workers on its own GPU (through that GPU's L2) and by workers on other GPUs (over xGMI,
+    at the memory): ordinary device memory is made coherent between the two only at kernel boundaries, uncached
+    (fine-grained) memory always is.  The allocation lives as long as the ps task."""
+    from .xgmi import _alloc, _export as export_handle
+
+    with torch.cuda.device(dev):
+        ptr = _alloc(rows * cols * 4, True)
+    return pickle.dumps({"handle": export_handle(ptr), "rows": rows, "cols": cols})
 
 
-def _import(blob: bytes) -> torch.Tensor:
-    fn, args = pickle.loads(blob)   # produced by _export() in the ps task of the same job
-    return fn(*args)
+def _import(blob: bytes, device: torch.device) -> torch.Tensor:
+    """Maps a shard published by ``_allocate_shard`` into this process, as a tensor of ``device``'s kernels."""
+    from .xgmi import _DeviceBuffer, _open
+
+    d = pickle.loads(blob)      # produced by _allocate_shard() in the ps task of the same job
+    with torch.cuda.device(device):
+        ptr = _open(d["handle"])
+        buf = _DeviceBuffer(ptr, d["rows"] * d["cols"] * 4, "<f4", 4, False)
+        return torch.as_tensor(buf, device=device).view(d["rows"], d["cols"])
 
 
 def serve_ipc_shard(server, poll: float = 0.2) -> bool:
@@ -71,13 +84,12 @@ def serve_ipc_shard(server, poll: float = 0.2) -> bool:
     Waits for the chief's allocation request ({numel, rows}), allocates
     ``rows x numel`` floats on this task's GPU (row 0 = the variables, rows 1..N
     = one gradient mailbox per worker), publishes the IPC handle and then
-    blocks until the cluster releases the task.  The tensor stays alive for the
-    lifetime of the process, which keeps the mapping valid in the workers.
+    blocks until the cluster releases the task.  The allocation is never freed:
+    it lives as long as the process, which keeps the mapping valid in the workers.
     """
     from ..runtime import native as rt
 
     me = rt.StoreClient("127.0.0.1", server.port, timeout=30)
-    keep = []
     try:
         while True:
             if server._native.wait(0.0):
@@ -90,11 +102,9 @@ def serve_ipc_shard(server, poll: float = 0.2) -> bool:
             dev = server.device
             if dev.type != "cuda":
                 raise RuntimeError("transport='ipc' needs a GPU in the ps task")
-            slab = torch.zeros((rows, max(numel, 4)), dtype=torch.float32, device=dev)
-            torch.cuda.synchronize(dev)
-            keep.append(slab)
+            blob = _allocate_shard(rows, max(numel, 4), dev)
             me.qpush(LOCK_Q, b"1")                 # the shard mutex starts released
-            me.set(HANDLE_KEY, _export(slab))
+            me.set(HANDLE_KEY, blob)
             me.delete(ALLOC_KEY)
             if server.config.log_device_placement:
                 print(f"[ps {server.task_index}] shard of {numel} floats + {rows - 1} mailboxes resident on {dev}",
@@ -143,9 +153,8 @@ class IpcVariableStore:
         m = self._maps[k]
         if m is None:
             blob = self._c(k).get(HANDLE_KEY, timeout=self.timeout)
-            m = _import(blob)
-            # a shard in another GPU's HBM: the worker's kernels (SGD push, initialisers) write through it
-            hb.enable_peer_access(self.device, m.device)
+            # (a shard in another GPU's HBM is mapped with peer access enabled by the open call itself)
+            m = _import(blob, self.device)
             self._maps[k] = m
         return m
 
