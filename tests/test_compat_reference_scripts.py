@@ -26,9 +26,9 @@ def _env(extra=None):
     return env
 
 
-def _run(script, args=(), env=None, cwd=None):
+def _run(script, args=(), env=None, cwd=None, sets=()):
     cmd = [sys.executable, "-u", "-m", "distributed_tensorflow_amd.compat.run", os.path.join(REF, script),
-           "--dtf-set", "epochs=1", *args]
+           "--dtf-set", "epochs=1", *[a for s in sets for a in ("--dtf-set", s)], *args]
     return subprocess.Popen(cmd, cwd=cwd, env=env or _env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -41,13 +41,18 @@ def test_reference_tfsingle_runs_unmodified(tmp_path):
     assert any(f.startswith("events.out.tfevents") for f in os.listdir(tmp_path / "logs"))
 
 
-@pytest.mark.parametrize("script,sync", [("tfdist_between.py", False), ("tfdist_between_sync.py", True)])
+@pytest.mark.parametrize("script,sync", [("tfdist_between.py", False), ("tfdist_between_sync.py", True),
+                                         ("tfdist.py", False)])
 def test_reference_between_graph_scripts_run_unmodified(script, sync, tmp_path):
+    """``tfdist.py`` is the reference's first between-graph script: the cluster addresses are module constants
+    (tfdist.py:8-9: two machines of its authors) instead of ``settings.py``, the server gets no ConfigProto and the
+    worker device names no GPU (tfdist.py:16,33); only those two address lists are replaced."""
     c = cluster_dict(1, 2)
     env = _env({"DTF_PS_SVRS": ",".join(c["ps"]), "DTF_WORKER_SVRS": ",".join(c["worker"])})
-    procs = {"ps0": _run(script, ["--job_name=ps", "--task_index=0"], env, str(tmp_path))}
+    sets = (f"ps_svrs={c['ps']!r}", f"worker_svrs={c['worker']!r}") if script == "tfdist.py" else ()
+    procs = {"ps0": _run(script, ["--job_name=ps", "--task_index=0"], env, str(tmp_path), sets)}
     for i in range(2):
-        procs[f"w{i}"] = _run(script, ["--job_name=worker", f"--task_index={i}"], env, str(tmp_path))
+        procs[f"w{i}"] = _run(script, ["--job_name=worker", f"--task_index={i}"], env, str(tmp_path), sets)
     outs = {}
     try:
         for k, p in procs.items():
