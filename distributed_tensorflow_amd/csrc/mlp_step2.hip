@@ -6,7 +6,12 @@
 //                                        and (fused mode) the SGD update          (F4-F12, G1-G7, U1-U2)
 //   two launches, synchronous replicas on several GPUs (dtf_mlp_step_xg)
 //     launch 2' bwd_tile16_xg            launch 2 in fused mode whose threads first swap their gradient
-//                                        element with the same thread of every peer replica (see XgParams)
+//                                        element with the same thread of every peer replica (see XgParams;
+//                                        8-byte {number, value} words, or bare 4-byte values: xg_exchange_compact)
+//   two launches, asynchronous worker against parameter-server shards (dtf_mlp_step_async)
+//     launch 2" bwd_tile16_xg<.., -1>    launch 2 whose threads add -lr * (their gradient element) to the shard
+//                                        that owns the variable, with float atomics through peer / IPC
+//                                        mappings (see xa_push); the worker's own copy is only read
 //   one launch per step (fused single-GPU training; dtf_mlp_chunk_pipelined)
 //     step_pipe                          launch 2 of step t ++ launch 1 of step t+1, see its comment
 // (op numbers: the reference graph, tfdist_between.py:55-70).
