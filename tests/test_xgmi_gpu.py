@@ -147,3 +147,37 @@ def test_one_launch_pull_over_shards_of_different_sizes():
     assert torch.equal(local, torch.cat(shards))
     st_bad = (C.c_int64 * len(starts))(*[s + 2 if 0 < i < len(sizes) else s for i, s in enumerate(starts)])
     assert hb.require().dtf_xgmi_pull_ranges(ptrs, st_bad, len(sizes), local.data_ptr(), None) != 0   # unaligned range
+
+
+@pytest.mark.gpu
+def test_pushing_backward_matches_the_fp32_oracle():
+    """Three steps of one asynchronous worker (push inside the backward launch) against plain PyTorch fp32:
+    p <- p - lr * grad(batch) with the gradients of ``ops/reference.py``, and global_step counting the pushes."""
+    import torch
+
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(400, 784, generator=g)
+    y = torch.eye(10)[torch.randint(0, 10, (400,), generator=g)]
+    ds = DeviceDataset(x, y, dev, 100, seed=3)
+    lr = 0.05
+    t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=lr, seed=1, rank=0, world=1,
+                              chunk=4, use_graph=False, fused_push=True)
+    p = {k: v.clone() for k, v in t.layout.mlp_views(t.params).items()}
+    for step in range(3):
+        xb, yb = ds.x_epoch[100 * step:100 * (step + 1)], ds.y_epoch[100 * step:100 * (step + 1)]
+        gr = ref.mlp_grads(xb, yb, p["W1"], p["b1"], p["W2"], p["b2"])
+        for k in ("W1", "b1", "W2", "b2"):
+            p[k] = p[k] - lr * gr["d" + k]
+    t.run_steps(3)
+    torch.cuda.synchronize()
+    assert t.global_step_value() == 3               # (pulls the shards into t.params)
+    got = t.layout.mlp_views(t.params)
+    for k in ("W1", "b1", "W2", "b2"):
+        err = float((got[k] - p[k]).abs().max())
+        assert err <= 2e-5 * max(1.0, float(p[k].abs().max())), (k, err)
+    t.close()
