@@ -45,7 +45,7 @@ import torch
 
 from ..ops import hip_backend as hb
 from ..variables import ShardLayout
-from .store import FINISHED_KEY, INIT_KEY, spread_tokens, token_key
+from .store import FINISHED_KEY, INIT_KEY, TOKEN_Q, spread_tokens, token_key
 
 ALLOC_KEY = "__ipc_alloc__"
 HANDLE_KEY = "__ipc_handle__"
@@ -346,7 +346,12 @@ class IpcVariableStore:
 
     def enqueue_tokens(self, clients, step: int, n: int):
         tok = struct.pack("<q", int(step))
-        for w, copies in enumerate(spread_tokens(n, self.n_workers)):
+        per_worker = spread_tokens(n, self.n_workers)
+        if per_worker[0] > 0 and len(set(per_worker)) == 1:
+            # the usual round (replicas_to_aggregate == number of workers): one request feeds every worker's queue
+            clients[self._gs_shard].qpush_fanout(TOKEN_Q, tok, self.n_workers, copies=per_worker[0])
+            return
+        for w, copies in enumerate(per_worker):
             if copies:
                 clients[self._gs_shard].qpush(token_key(w), tok, copies=copies)
 

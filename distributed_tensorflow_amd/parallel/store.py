@@ -231,7 +231,12 @@ class RemoteVariableStore:
 
     def enqueue_tokens(self, clients, step: int, n: int):
         tok = struct.pack("<q", int(step))
-        for w, copies in enumerate(spread_tokens(n, self.n_workers)):
+        per_worker = spread_tokens(n, self.n_workers)
+        if per_worker[0] > 0 and len(set(per_worker)) == 1:
+            # the usual round (replicas_to_aggregate == number of workers): one request feeds every worker's queue
+            clients[self._gs_shard].qpush_fanout(TOKEN_Q, tok, self.n_workers, copies=per_worker[0])
+            return
+        for w, copies in enumerate(per_worker):
             if copies:
                 clients[self._gs_shard].qpush(token_key(w), tok, copies=copies)
 

@@ -16,6 +16,7 @@ extern "C" {
 
 // request flags
 #define DTF_FLAG_LOCK 1
+#define DTF_FLAG_FANOUT 2   /* QPUSH: key is a prefix, the payload goes to the queues key/0 .. key/(a1-1) */
 
 // operations
 #define DTF_OP_PING 0

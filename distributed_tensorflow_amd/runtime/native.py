@@ -21,6 +21,7 @@ _lib = None
 
 OK, TIMEOUT, BAD_REQUEST, IO_ERROR, TOO_SMALL = 0, 1, 2, 3, 4
 FLAG_LOCK = 1
+FLAG_FANOUT = 2
 (OP_PING, OP_SET, OP_GET, OP_ADD, OP_WAIT_GE, OP_QPUSH, OP_QPOP, OP_DEL, OP_SHUTDOWN, OP_QLEN,
  OP_BUF_CREATE, OP_BUF_WRITE, OP_BUF_READ, OP_BUF_AXPY, OP_ACC_APPLY, OP_ACC_TAKE_APPLY, OP_ACC_SET_STEP,
  OP_BUF_ADD_SCALAR, OP_ACC_INFO) = range(19)
@@ -199,6 +200,12 @@ class StoreClient:
     def qpush(self, key: str, value: bytes, copies: int = 1) -> int:
         st, v, _ = self._call(OP_QPUSH, key, a0=copies, payload=value)
         self._ok(st, f"qpush {key}")
+        return v
+
+    def qpush_fanout(self, prefix: str, value: bytes, fanout: int, copies: int = 1) -> int:
+        """``copies`` of ``value`` into each of the queues ``prefix/0 .. prefix/(fanout-1)`` in ONE request."""
+        st, v, _ = self._call(OP_QPUSH, prefix, flags=FLAG_FANOUT, a0=copies, a1=fanout, payload=value)
+        self._ok(st, f"qpush_fanout {prefix}")
         return v
 
     def qpop(self, key: str, timeout: float = 60.0) -> bytes:

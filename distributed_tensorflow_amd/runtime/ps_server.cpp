@@ -241,6 +241,23 @@ void serve_connection(Server* s, Server::Conn* self) {
         break;
       }
       case DTF_OP_QPUSH: {
+        if (h.flags & DTF_FLAG_FANOUT) {
+          // one request feeds the queue of every worker (the chief's token release): a0 copies each into
+          // key/0 .. key/(a1-1)
+          const int64_t copies = h.a0 > 0 ? h.a0 : 1;
+          if (h.a1 < 0 || h.a1 > 65536) {
+            r.status = DTF_RT_BAD_REQUEST;
+            break;
+          }
+          for (int64_t w = 0; w < h.a1; ++w) {
+            auto e = s->get(key + "/" + std::to_string(w), true);
+            std::lock_guard<std::mutex> g(e->mu);
+            for (int64_t i = 0; i < copies; ++i) e->queue.push_back(payload);
+            e->cv.notify_all();
+          }
+          r.value = h.a1;
+          break;
+        }
         auto e = s->get(key, true);
         std::lock_guard<std::mutex> g(e->mu);
         const int64_t copies = h.a0 > 0 ? h.a0 : 1;

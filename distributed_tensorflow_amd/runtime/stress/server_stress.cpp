@@ -110,8 +110,12 @@ int main(int argc, char** argv) {
       } while (rc == DTF_RT_TIMEOUT);
       CHECK(rc == DTF_RT_OK && taken == workers, "take_apply rc=%d taken=%lld", rc, (long long)taken);
       int64_t step = r + 1;
-      for (int w = 0; w < workers; ++w)
-        c.call(DTF_OP_QPUSH, "tok/" + std::to_string(w), 0, 1, 0, 0.0, &step, sizeof(step));
+      if (r & 1) {   // odd rounds: one fan-out request for all workers' queues, even rounds: one request per queue
+        c.call(DTF_OP_QPUSH, "tok", DTF_FLAG_FANOUT, 1, workers, 0.0, &step, sizeof(step));
+      } else {
+        for (int w = 0; w < workers; ++w)
+          c.call(DTF_OP_QPUSH, "tok/" + std::to_string(w), 0, 1, 0, 0.0, &step, sizeof(step));
+      }
     }
   });
 

@@ -41,6 +41,15 @@ def test_kv_counters_queues(server):
     assert a.qlen("q") == 3 and struct.unpack("<q", b.qpop("q"))[0] == 7 and a.qlen("q") == 2
     with pytest.raises(TimeoutError):
         a.qpop("empty", timeout=0.05)
+    # one request feeds a queue per worker (the chief's token release); a waiting consumer is woken
+    woken = []
+    t = threading.Thread(target=lambda: woken.append(b.qpop("tok/2", timeout=5)))
+    t.start()
+    time.sleep(0.05)
+    assert a.qpush_fanout("tok", struct.pack("<q", 41), fanout=3, copies=2) == 3
+    t.join()
+    assert woken == [struct.pack("<q", 41)]
+    assert [a.qlen(f"tok/{w}") for w in range(4)] == [2, 2, 1, 0]
     # blocking get is released by a later set (event-driven wait-for-init)
     t0 = time.time()
     res = []
