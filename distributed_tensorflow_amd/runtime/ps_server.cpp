@@ -25,6 +25,7 @@
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -79,16 +80,41 @@ bool read_full(int fd, void* buf, size_t n) {
   }
   return true;
 }
-bool write_full(int fd, const void* buf, size_t n) {
-  const char* p = static_cast<const char*>(buf);
-  while (n > 0) {
-    ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL);
+// Header, key and payload of a message leave in ONE system call (and, small as the control messages are, in one
+// TCP segment): with TCP_NODELAY three separate sends are three segments and three wake-ups of the receiver.
+bool write_parts(int fd, const void* a, size_t na, const void* b, size_t nb, const void* c, size_t nc) {
+  struct iovec iov[3];
+  int cnt = 0;
+  auto add = [&](const void* p, size_t n) {
+    if (n) {
+      iov[cnt].iov_base = const_cast<void*>(p);
+      iov[cnt].iov_len = n;
+      ++cnt;
+    }
+  };
+  add(a, na);
+  add(b, nb);
+  add(c, nc);
+  int first = 0;
+  while (first < cnt) {
+    struct msghdr msg;
+    std::memset(&msg, 0, sizeof(msg));
+    msg.msg_iov = iov + first;
+    msg.msg_iovlen = static_cast<size_t>(cnt - first);
+    ssize_t r = ::sendmsg(fd, &msg, MSG_NOSIGNAL);
     if (r < 0) {
       if (errno == EINTR) continue;
       return false;
     }
-    p += r;
-    n -= static_cast<size_t>(r);
+    size_t done = static_cast<size_t>(r);
+    while (first < cnt && done >= iov[first].iov_len) {
+      done -= iov[first].iov_len;
+      ++first;
+    }
+    if (first < cnt && done) {
+      iov[first].iov_base = static_cast<char*>(iov[first].iov_base) + done;
+      iov[first].iov_len -= done;
+    }
   }
   return true;
 }
@@ -427,8 +453,7 @@ void serve_connection(Server* s, Server::Conn* self) {
         r.status = DTF_RT_BAD_REQUEST;
     }
     r.payload_len = out.size();
-    if (!write_full(fd, &r, sizeof(r))) break;
-    if (!out.empty() && !write_full(fd, out.data(), out.size())) break;
+    if (!write_parts(fd, &r, sizeof(r), out.data(), out.size(), nullptr, 0)) break;
     s->bytes_out += sizeof(r) + out.size();
   }
   {
@@ -615,9 +640,7 @@ int dtf_client_call(void* h, int op, const char* key, int flags, int64_t a0, int
   std::lock_guard<std::mutex> g(c->mu);
   ReqHeader req{kMagic, static_cast<uint32_t>(op), static_cast<uint32_t>(key ? strlen(key) : 0),
                 static_cast<uint32_t>(flags), a0, a1, f0, payload_len};
-  if (!write_full(c->fd, &req, sizeof(req))) return DTF_RT_IO_ERROR;
-  if (req.key_len && !write_full(c->fd, key, req.key_len)) return DTF_RT_IO_ERROR;
-  if (payload_len && !write_full(c->fd, payload, payload_len)) return DTF_RT_IO_ERROR;
+  if (!write_parts(c->fd, &req, sizeof(req), key, req.key_len, payload, payload_len)) return DTF_RT_IO_ERROR;
   RespHeader r;
   if (!read_full(c->fd, &r, sizeof(r))) return DTF_RT_IO_ERROR;
   if (out_value) *out_value = r.value;
