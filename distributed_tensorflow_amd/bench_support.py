@@ -196,6 +196,14 @@ def run_benchmark(args) -> Optional[dict]:
                 dt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=device)
                 if distributed:
                     dist.all_reduce(dt, op=dist.ReduceOp.MAX)     # identical decision on every rank
+                if cand in PEER_MODES:
+                    # an exchange that gave up on a peer skips its work from then on and would look FAST
+                    sane = torch.tensor([1 if t.healthy() else 0], dtype=torch.int32, device=device)
+                    if distributed:
+                        dist.all_reduce(sane, op=dist.ReduceOp.MIN)
+                    if not int(sane.item()):
+                        retire(t)       # (every rank is here: the verdict was reduced over all of them)
+                        raise RuntimeError("an exchange timed out during the probe")
             except Exception as e:  # noqa: BLE001 — a candidate that cannot run here is simply not chosen
                 print(f"[bench rank {rank}] candidate {cand} failed ({type(e).__name__}: {e})", file=sys.stderr,
                       flush=True)
