@@ -150,6 +150,7 @@ int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const fl
 int dtf_xgmi_fill(void* p, int byte, int64_t bytes);
 int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int world, float* local, void* stream);
 
+int dtf_abi_sizeof(int which);   // sizeof of DtfMlpDesc (0), DtfPipeDesc (1), DtfXgDesc (2)
 const char* dtf_hip_build_info(void);
 
 #ifdef __cplusplus

@@ -133,6 +133,16 @@ extern "C" int dtf_mlp_eval(const float* x, const float* y, int M, int K, int H,
   return dtf_launch_head(h, s);
 }
 
+// Sizes of the descriptor structs, for bindings that mirror them (0: mlp, 1: pipelined chunk, 2: cross-replica).
+extern "C" int dtf_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(DtfMlpDesc);
+    case 1: return (int)sizeof(DtfPipeDesc);
+    case 2: return (int)sizeof(DtfXgDesc);
+    default: return -1;
+  }
+}
+
 extern "C" const char* dtf_hip_build_info(void) {
   return "libdtf_hip gfx950 fp32-mfma " __DATE__ " " __TIME__;
 }

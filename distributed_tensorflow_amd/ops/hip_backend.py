@@ -157,6 +157,15 @@ def load(required: bool = False) -> Optional[C.CDLL]:
                     raise OSError(f"{_LIB_PATH} not built and the in-tree build failed: {e}") from None
             lib = C.CDLL(str(_LIB_PATH), mode=C.RTLD_GLOBAL)
             _declare(lib)
+            # the ctypes mirrors must have the library's layout: a stale .so next to newer Python (or the reverse)
+            # would otherwise read descriptor fields at the wrong offsets
+            lib.dtf_abi_sizeof.argtypes = [C.c_int]
+            lib.dtf_abi_sizeof.restype = C.c_int
+            for which, mirror in enumerate((DtfMlpDesc, DtfPipeDesc, DtfXgDesc)):
+                if lib.dtf_abi_sizeof(which) != C.sizeof(mirror):
+                    raise OSError(f"{_LIB_PATH} was built from other sources: sizeof({mirror.__name__}) is "
+                                  f"{lib.dtf_abi_sizeof(which)} there and {C.sizeof(mirror)} here; rebuild with "
+                                  f"python -m distributed_tensorflow_amd.build")
             _lib = lib
             return _lib
         except OSError as e:  # pragma: no cover - depends on the machine
