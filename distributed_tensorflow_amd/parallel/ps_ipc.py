@@ -342,7 +342,9 @@ class IpcVariableStore:
         stream.synchronize()
         self._arrived = []
         self._acc_step += 1
-        return self.global_step()
+        # == global_step: read from the shard when the aggregation began, bumped once per round by the last apply
+        # above (no device-to-host copy on the path every replica is waiting on)
+        return self._acc_step
 
     def enqueue_tokens(self, clients, step: int, n: int):
         tok = struct.pack("<q", int(step))
