@@ -92,6 +92,14 @@ int dtf_dw_gemm(const float* x, const float* dz, float* out, int M, int K, int H
 // global_step += 1 (single thread).
 int dtf_sgd_apply(float* p, float* g, int64_t n, const float* lr, float scale,
                   int zero_grad, float* global_step, void* stream);
+// The same update with one float atomic per element: concurrent applies to one shard lose no update
+// (use_locking=True for shards that several service streams update at once).
+int dtf_sgd_apply_atomic(float* p, const float* g, int64_t n, const float* lr, float scale, float* global_step,
+                         void* stream);
+// p[i] -= lr * scale * (g_0[i] + ... + g_{count-1}[i]) in one launch (sum in index order); global_step += 1.
+// grads: HOST array of `count` <= 16 device addresses.
+int dtf_sum_apply(float* p, const uint64_t* grads, int count, int64_t n, const float* lr, float scale,
+                  float* global_step, void* stream);
 // acc[i] += g[i]
 int dtf_accumulate(float* acc, const float* g, int64_t n, void* stream);
 // Philox4x32-10 + Box-Muller normal fill: out[i] = mean + std * N(0,1), a pure

@@ -50,6 +50,56 @@ __global__ __launch_bounds__(kBlock) void sgd_apply_kernel(float* __restrict__ p
   }
 }
 
+// The same update for a shard that several service streams update at once (use_locking=True): every element
+// is one float atomic, so concurrent applies interleave per element and none is lost.  (The unlocked kernel
+// above reads, subtracts and writes whole vectors: concurrent applies may overwrite each other, which is the
+// meaning of use_locking=False in the reference, tfdist_between.py:65.)
+__global__ __launch_bounds__(kBlock) void sgd_apply_atomic_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                  int64_t n, const float* __restrict__ lr_ptr,
+                                                                  float scale, float* global_step) {
+  const float a = -(*lr_ptr) * scale;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    (void)__hip_atomic_fetch_add(p + i, a * g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && global_step) atomicAdd(global_step, 1.0f);
+}
+
+// SyncReplicas aggregation in ONE launch: p -= lr * scale * (g_0 + g_1 + ... + g_{N-1}), the N gradient
+// mailboxes summed in index order (take_grad of every accumulator + ApplyGradientDescent + the step bump,
+// tfdist_between_sync.py:65-68), instead of N SGD launches.
+constexpr int kMaxSources = 16;
+struct SumApplyArgs {
+  const float* g[kMaxSources];
+  int count;
+};
+
+__global__ __launch_bounds__(kBlock) void sum_apply_kernel(float* __restrict__ p, SumApplyArgs s, int64_t n,
+                                                           const float* __restrict__ lr_ptr, float scale,
+                                                           float* global_step) {
+  const float a = (*lr_ptr) * scale;
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+    f32x4 sum = reinterpret_cast<const f32x4*>(s.g[0])[i];
+#pragma unroll
+    for (int k = 1; k < kMaxSources; ++k)
+      if (k < s.count) sum = sum + reinterpret_cast<const f32x4*>(s.g[k])[i];
+    p4[i] = p4[i] - a * sum;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t t = (nvec << 2) + threadIdx.x;
+    if (t < n) {
+      float sum = s.g[0][t];
+#pragma unroll
+      for (int k = 1; k < kMaxSources; ++k)
+        if (k < s.count) sum += s.g[k][t];
+      p[t] -= a * sum;
+    }
+    if (threadIdx.x == 0 && global_step) atomicAdd(global_step, 1.0f);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void accumulate_kernel(float* __restrict__ acc,
                                                             const float* __restrict__ g, int64_t n) {
   const int64_t nvec = n >> 2;
@@ -155,6 +205,31 @@ extern "C" int dtf_sgd_apply(float* p, float* g, int64_t n, const float* lr, flo
   if (!aligned16(p) || !aligned16(g)) return DTF_ERR_SHAPE;
   hipLaunchKernelGGL(sgd_apply_kernel, dim3(grid_for(n >> 2)), dim3(kBlock), 0, (hipStream_t)stream, p,
                      g, n, lr, scale, zero_grad, global_step);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_sgd_apply_atomic(float* p, const float* g, int64_t n, const float* lr, float scale,
+                                    float* global_step, void* stream) {
+  if (!p || !g || !lr) return DTF_ERR_NULL;
+  if (n < 0) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(sgd_apply_atomic_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, g, n, lr,
+                     scale, global_step);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+// grads: HOST array of `count` device addresses (1 <= count <= 16), every one n floats, 16-byte aligned.
+extern "C" int dtf_sum_apply(float* p, const uint64_t* grads, int count, int64_t n, const float* lr, float scale,
+                             float* global_step, void* stream) {
+  if (!p || !grads || !lr) return DTF_ERR_NULL;
+  if (n < 0 || count < 1 || count > kMaxSources || !aligned16(p)) return DTF_ERR_SHAPE;
+  SumApplyArgs s;
+  for (int k = 0; k < kMaxSources; ++k) {
+    s.g[k] = reinterpret_cast<const float*>(grads[k < count ? k : 0]);
+    if (!s.g[k] || !aligned16(s.g[k])) return DTF_ERR_NULL;
+  }
+  s.count = count;
+  hipLaunchKernelGGL(sum_apply_kernel, dim3(grid_for(n >> 2)), dim3(kBlock), 0, (hipStream_t)stream, p, s, n, lr,
+                     scale, global_step);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

@@ -106,6 +106,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_dw_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp]
     lib.dtf_sgd_apply.argtypes = [vp, vp, i64, vp, f32, i32, vp, vp]
     lib.dtf_accumulate.argtypes = [vp, vp, i64, vp]
+    lib.dtf_sgd_apply_atomic.argtypes = [vp, vp, i64, vp, f32, vp, vp]
+    lib.dtf_sgd_apply_atomic.restype = C.c_int
+    lib.dtf_sum_apply.argtypes = [vp, vp, i32, i64, vp, f32, vp, vp]
+    lib.dtf_sum_apply.restype = C.c_int
     lib.dtf_philox_normal.argtypes = [vp, i64, u64, u64, f32, f32, vp]
     lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.dtf_hip_build_info.restype = C.c_char_p
@@ -263,6 +267,39 @@ def sgd_apply_(p, g, lr: torch.Tensor, scale: float = 1.0, zero_grad: bool = Fal
         raise HipKernelError("sgd_apply: size mismatch")
     _check(lib.dtf_sgd_apply(_ptr(p), _ptr(g), p.numel(), _ptr(lr), float(scale), int(zero_grad),
                              _ptr(global_step), _stream()), "dtf_sgd_apply")
+    return p
+
+
+def sgd_apply_atomic_(p, g, lr: torch.Tensor, scale: float = 1.0, global_step: Optional[torch.Tensor] = None):
+    """``p -= lr * scale * g`` with one float atomic per element (no update lost under concurrent applies)."""
+    lib = require()
+    _f32c(p, "p"), _f32c(g, "g"), _f32c(lr, "lr")
+    if p.numel() != g.numel():
+        raise HipKernelError("sgd_apply_atomic: size mismatch")
+    _check(lib.dtf_sgd_apply_atomic(_ptr(p), _ptr(g), p.numel(), _ptr(lr), float(scale), _ptr(global_step),
+                                    _stream()), "dtf_sgd_apply_atomic")
+    return p
+
+
+def sum_apply_(p, grads, lr: torch.Tensor, scale: float = 1.0, global_step: Optional[torch.Tensor] = None):
+    """``p -= lr * scale * sum(grads)`` in ONE launch; ``grads``: up to 16 tensors shaped like ``p`` (or their
+    device addresses), summed in list order."""
+    lib = require()
+    _f32c(p, "p"), _f32c(lr, "lr")
+    ptrs = []
+    for g in grads:
+        if isinstance(g, torch.Tensor):
+            _f32c(g, "grad")
+            if g.numel() != p.numel():
+                raise HipKernelError("sum_apply: size mismatch")
+            ptrs.append(g.data_ptr())
+        else:
+            ptrs.append(int(g))
+    if not 1 <= len(ptrs) <= 16:
+        raise HipKernelError("sum_apply: 1..16 gradient sources")
+    tab = (C.c_uint64 * len(ptrs))(*ptrs)
+    _check(lib.dtf_sum_apply(_ptr(p), tab, len(ptrs), p.numel(), _ptr(lr), float(scale), _ptr(global_step),
+                             _stream()), "dtf_sum_apply")
     return p
 
 

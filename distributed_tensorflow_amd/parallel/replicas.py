@@ -15,10 +15,16 @@ One process per GPU.  Every process is worker *r* AND the owner of PS shard *r*
 * ``TowerTrainer``    — in-graph-replication semantics (one logical client, N
   towers): gradients are all-reduce-averaged over RCCL and every tower applies
   the identical update to its replica of the variables.
-* ``AsyncAllToAllTrainer`` — asynchronous update *rule* (every worker's gradient
+* ``LockstepAsyncRuleTrainer`` — asynchronous update *rule* (every worker's gradient
   is applied separately, unaveraged, to the owning shard; ``global_step``
-  advances by N per round) executed in lock step with collectives.  The truly
-  unsynchronised variant lives in :mod:`parallel.ps_ipc`.
+  advances by N per round) executed in LOCK STEP with collectives: a reference
+  point for the arithmetic, not an asynchronous transport.
+* ``AsyncSendRecvTrainer`` — between-graph ASYNCHRONOUS parameter servers over
+  two-sided library point-to-point calls (RCCL ``ncclSend`` / ``ncclRecv`` on the
+  GPUs, gloo in CPU tests): one communicator and one service stream (or thread)
+  per (worker, shard) pair, so a worker only ever waits for the shard owner's
+  service of ITS OWN request.  The library baseline of the one-sided
+  ``XgmiAsyncTrainer``.
 
 Collectives go through ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI
 on the GPUs, ``gloo`` in CPU tests).  The message is 318 KB, i.e. latency-bound:
@@ -301,10 +307,12 @@ class TowerTrainer(_CollectiveTrainer):
             (", hipGraph" if self.use_graph else ", eager")
 
 
-class AsyncAllToAllTrainer(_CollectiveTrainer):
-    """Async update rule in lock step: shard owners apply each worker's gradient separately."""
+class LockstepAsyncRuleTrainer(_CollectiveTrainer):
+    """Async update RULE in lock step: shard owners apply each worker's gradient separately, but all workers
+    move through all-to-all / all-gather together.  Not an asynchronous transport (see AsyncSendRecvTrainer,
+    XgmiAsyncTrainer for those)."""
 
-    name = "async"
+    name = "async_lockstep"
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -323,8 +331,180 @@ class AsyncAllToAllTrainer(_CollectiveTrainer):
             self._apply(self.my_params, self.my_grads, 1.0, bump=self.owns_step)
 
     def describe(self):
-        return (f"async-rule dp{self.world}: all-to-all gradient push, per-worker unaveraged apply on the "
-                f"owning shard, all-gather pull" + (", hipGraph" if self.use_graph else ", eager"))
+        return (f"async-rule (lock step) dp{self.world}: all-to-all gradient push, per-worker unaveraged apply on "
+                f"the owning shard, all-gather pull" + (", hipGraph" if self.use_graph else ", eager"))
+
+
+class AsyncSendRecvTrainer(_CollectiveTrainer):
+    """Asynchronous parameter servers over two-sided point-to-point calls (``--mode async_rccl``).
+
+    Rank r is worker r and owns shard r of the flat slab.  One worker step (reference tfdist_between.py:56-58,
+    65-66: pull, compute, push, apply on the variable's device):
+
+        forward + backward on the worker's private copy of the variables
+        for every shard k:  send grad[range k] -> owner k ;  recv fresh params[range k] <- owner k
+
+    and, independently, the owner of shard k serves every worker w on a SERVICE lane of its own:
+
+        recv g <- w ;  shard_k -= lr * g  (SGD kernel on the service stream; global_step += 1 on the shard that
+        holds it) ;  send shard_k -> w
+
+    Every ordered (worker, shard) pair has its own 2-rank communicator, so a request is matched by nothing but
+    the owner's service lane for that worker: no worker waits for another worker, and the parameters a worker
+    receives contain whatever other workers' updates the shard had absorbed by then (staleness <= N - 1
+    updates, unbounded in wall time).  ``use_locking=False`` (the reference's default) lets the service lanes'
+    whole-vector updates of one shard interleave; ``use_locking=True`` applies with float atomics (GPU) or under
+    a mutex (CPU) so that no update is lost.
+
+    With RCCL the calls are stream-ordered: ``run_steps(n)`` enqueues the worker's n steps on the current
+    stream and the n services per worker on side streams and returns; nothing blocks the host.  With gloo the
+    calls block, so the services run in threads for the duration of ``run_steps``.  Every rank must call
+    ``run_steps`` with the same n (each owner serves exactly n requests per worker).
+    """
+
+    name = "async_rccl"
+
+    def __init__(self, *a, use_locking: bool = False, **kw):
+        kw["use_graph"] = False          # point-to-point calls on several communicators: eager launches
+        super().__init__(*a, **kw)
+        d = self.dist
+        self.use_locking = bool(use_locking)
+        self.backend = d.get_backend() if self.world > 1 else "none"
+        self.stream_ordered = self.backend == "nccl"
+        # the authoritative copy of this rank's shard (the worker trains on self.params, a private copy)
+        self.shard = self.my_params.clone()
+        a0, b0 = self.layout.shard_range[self.rank]
+        o, _ = self.layout.var_range["global_step"]
+        self.shard_step = self.shard[o - a0:o - a0 + 1] if self.owns_step else None
+        n = self.layout.shard_numel(self.rank)
+        self.inbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
+        self.outbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
+        # pair[(w, k)]: worker w <-> owner k; every rank creates every group, in the same order
+        self.pair = {}
+        if self.world > 1:
+            for w in range(self.world):
+                for k in range(self.world):
+                    if w != k:
+                        self.pair[(w, k)] = d.new_group([w, k])
+        self._lock = None
+        if not self.stream_ordered:
+            import threading
+
+            self._lock = threading.Lock()
+        self._side = {}
+        if self.stream_ordered:
+            self._side = {w: torch.cuda.Stream(device=self.device) for w in range(self.world) if w != self.rank}
+        self.served = 0
+
+    # -- the owner's side -----------------------------------------------------------------------------
+    def _apply_to_shard(self, g):
+        if self.device.type == "cuda":
+            if self.use_locking:
+                hb.sgd_apply_atomic_(self.shard, g, self.lr, 1.0, self.shard_step)
+            else:
+                hb.sgd_apply_(self.shard, g, self.lr, 1.0, False, self.shard_step)
+        elif self._lock is not None and self.use_locking:
+            with self._lock:
+                ref.sgd_apply_(self.shard, g, float(self.lr.item()), 1.0)
+                if self.shard_step is not None:
+                    self.shard_step.add_(1.0)
+        else:
+            ref.sgd_apply_(self.shard, g, float(self.lr.item()), 1.0)
+            if self.shard_step is not None:
+                self.shard_step.add_(1.0)
+        self.served += 1
+
+    def _serve_once(self, w: int):
+        d, grp = self.dist, self.pair[(w, self.rank)]
+        d.recv(self.inbox[w], src=w, group=grp)
+        self._apply_to_shard(self.inbox[w])
+        self.outbox[w].copy_(self.shard)          # a snapshot: the shard keeps changing under other lanes
+        d.send(self.outbox[w], dst=w, group=grp)
+
+    def _service_thread(self, w: int, n: int, errors: list):
+        try:
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
+            for _ in range(n):
+                self._serve_once(w)
+        except Exception as e:  # noqa: BLE001 — reported by run_steps on the main thread
+            errors.append((w, e))
+
+    # -- the worker's side ----------------------------------------------------------------------------
+    def _one_step(self, batch_index: int):
+        d = self.dist
+        self.engine.step_grad(batch_index, scale=1.0)
+        for k in range(self.world):
+            a, b = self.layout.shard_range[k]
+            if k == self.rank:
+                continue
+            grp = self.pair[(self.rank, k)]
+            d.send(self.grads[a:b], dst=k, group=grp)
+        # own shard: no communicator between a rank and itself
+        self._apply_to_shard(self.my_grads)
+        self.my_params.copy_(self.shard)
+        for k in range(self.world):
+            a, b = self.layout.shard_range[k]
+            if k == self.rank:
+                continue
+            d.recv(self.params[a:b], src=k, group=self.pair[(self.rank, k)])
+
+    def _run_eager(self, pos: int, n: int):
+        if self.world == 1:
+            return super()._run_eager(pos, n)
+        if self.stream_ordered:
+            main = torch.cuda.current_stream(self.device)
+            for s in self._side.values():
+                s.wait_stream(main)
+            for i in range(n):
+                self._one_step(pos + i)
+                for w, s in self._side.items():
+                    with torch.cuda.stream(s):
+                        self._serve_once(w)
+            self.engine.advance(n)
+            return
+        import threading
+
+        errors: list = []
+        threads = [threading.Thread(target=self._service_thread, args=(w, n, errors), daemon=True)
+                   for w in range(self.world) if w != self.rank]
+        for t in threads:
+            t.start()
+        for i in range(n):
+            self._one_step(pos + i)
+        for t in threads:
+            t.join()
+        if errors:
+            raise RuntimeError(f"service lane for worker {errors[0][0]} failed: {errors[0][1]}")
+        self.engine.advance(n)
+
+    def quiesce(self):
+        """Wait until every request enqueued so far has been served (side streams drained)."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            self.dist.barrier()
+
+    def evaluate(self, x, y):
+        self._refresh()
+        return self.engine.evaluate(x, y)
+
+    def _refresh(self):
+        """Private copy <- the authoritative shards (a collective: every rank calls it)."""
+        self.quiesce()
+        self.my_params.copy_(self.shard)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.params, self.shard.clone())
+
+    def global_step_value(self) -> int:
+        self._refresh()
+        return int(round(float(self.global_step.item())))
+
+    def describe(self):
+        lane = "side HIP stream" if self.stream_ordered else "service thread"
+        return (f"async PS dp{self.world} over {self.backend} send/recv: one communicator and one {lane} per "
+                f"(worker, shard) pair, owner applies with the SGD kernel "
+                f"({'atomic adds' if self.use_locking else 'unlocked whole-vector update'}), eager")
 
 
 class XgmiTowerTrainer(_BaseTrainer):
@@ -409,7 +589,8 @@ class XgmiFusedTrainer(_BaseTrainer):
 
     name = "xgmi2"
 
-    def __init__(self, *a, group=None, timeout_ms: int = 20000, compact: bool = False, **kw):
+    def __init__(self, *a, group=None, timeout_ms: int = 20000, compact: bool = False, local_peers: bool = False,
+                 **kw):
         kw["need_grads"] = False
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
@@ -421,11 +602,16 @@ class XgmiFusedTrainer(_BaseTrainer):
         self.compact = bool(compact)
         self.name = "xgmi2c" if self.compact else "xgmi2"
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
-                            timeout_ms=timeout_ms, compact=self.compact)
-        offs = {role: self.layout.var_range[name][0] for role, name in
-                (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
-                 ("b2", "biases/Variable_1"))}
-        self._xg_desc = self.xg.step_descriptor(offs)
+                            timeout_ms=timeout_ms, compact=self.compact, connect=not local_peers)
+        self._xg_offs = {role: self.layout.var_range[name][0] for role, name in
+                         (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
+                          ("b2", "biases/Variable_1"))}
+        self._xg_desc = None if local_peers else self.xg.step_descriptor(self._xg_offs)
+
+    def connect_local(self, towers):
+        """Replicas driven by ONE process (in-graph towers): wire the inboxes with plain pointers."""
+        self.xg.connect_local([t.xg for t in towers if t is not self])
+        self._xg_desc = self.xg.step_descriptor(self._xg_offs)
 
     def _one_step(self, batch_index: int):
         self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
@@ -544,7 +730,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async": AsyncAllToAllTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi2c": XgmiFusedTrainer,
+           "async_lockstep": LockstepAsyncRuleTrainer, "async_rccl": AsyncSendRecvTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi2c": XgmiFusedTrainer,
            "xgmi_async": XgmiAsyncTrainer}[mode]
     if mode == "xgmi2c":        # the exchange inside the backward launch with 4-byte words
         kw["compact"] = True

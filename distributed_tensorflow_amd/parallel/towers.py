@@ -1,7 +1,23 @@
 """In-graph replication: ONE client process driving a tower on every GPU.
 
 The reference abandoned this mode (README.md:261-264); it is provided here as
-its own design.  The single client holds one replica of the variables per
+its own design, in two forms:
+
+* :class:`InGraphEngine` — the engine.  Every tower has its own device, HIP
+  stream, replica of the variables, independently shuffled resident data set
+  and hipGraph chunks of the two-launch cross-replica step: the gradient mean
+  is taken INSIDE the towers' backward launches, every thread storing its
+  gradient element straight into the other towers' inboxes (peer access between
+  the GPUs of one process: plain pointers, no IPC handles) and polling its own.
+  The towers' graphs therefore need nothing from the host between them: the
+  client issues ONE graph launch per tower per chunk of steps and synchronises
+  only when it reads a cost.
+* :class:`InGraphTowers` — the library baseline: a host loop that launches the
+  fused forward/backward on every tower, all-reduces the gradient slabs with
+  ``torch.cuda.nccl.all_reduce`` (the single-process multi-GPU entry of RCCL)
+  and applies the sharded-SGD kernel on every tower.
+
+InGraphTowers: the single client holds one replica of the variables per
 tower, gives every tower its own mini-batch of the resident data set, and per
 step
 
@@ -133,6 +149,195 @@ class InGraphTowers:
     def replicas_identical(self) -> bool:
         ref0 = self.params[0].cpu()
         return all(torch.equal(ref0, p.cpu()) for p in self.params[1:])
+
+
+class InGraphEngine:
+    """One client, N towers, O(1) host calls per tower per chunk (see the module docstring).
+
+    ``exchange="inbox"``: gradient mean inside the backward launches (``compact=True``: 4-byte words);
+    ``exchange="rccl"``: the :class:`InGraphTowers` host loop (eager; the baseline).
+    Several towers may share one GPU (tests, one-GPU rehearsal): their kernels then have to be resident together,
+    which holds for up to 3 towers on an MI355X.
+    """
+
+    def __init__(self, devices: Sequence, images, labels, batch: int, lr: float, seed: int = 1, chunk: int = 50,
+                 exchange: str = "inbox", compact: bool = False, data_seed: int = 0, timeout_ms: int = 20000,
+                 use_graph: bool = True):
+        if exchange not in ("inbox", "rccl"):
+            raise ValueError(exchange)
+        self.devices = [torch.device(d) for d in devices]
+        self.n = len(self.devices)
+        self.exchange = exchange
+        self.chunk = max(1, int(chunk))
+        self.use_graph = bool(use_graph)
+        self._closed = False
+        if exchange == "rccl":
+            self._loop = InGraphTowers(self.devices, images, labels, batch, lr, seed=seed, data_seed=data_seed)
+            self.towers = []
+            return
+        if any(d.type != "cuda" for d in self.devices):
+            raise RuntimeError("the in-launch exchange is a GPU path")
+        from .replicas import XgmiFusedTrainer
+
+        distinct = sorted({d.index for d in self.devices})
+        for a in distinct:                      # kernels of every tower store into every other tower's inbox
+            for b in distinct:
+                hb.enable_peer_access(torch.device("cuda", a), torch.device("cuda", b))
+        self._loop = None
+        self.streams = []
+        self.towers = []
+        for t, dev in enumerate(self.devices):
+            with torch.cuda.device(dev):
+                st = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st):
+                    ds = DeviceDataset(images, labels, dev, batch, seed=data_seed + t)   # a different shuffle per tower
+                    tr = XgmiFusedTrainer(device=dev, dataset=ds, batch=batch, lr=lr, seed=seed, rank=t, world=self.n,
+                                          chunk=self.chunk, use_graph=self.use_graph, compact=compact,
+                                          timeout_ms=timeout_ms, local_peers=True)
+                st.synchronize()
+            self.streams.append(st)
+            self.towers.append(tr)
+        for tr in self.towers:
+            tr.connect_local(self.towers)
+        self.batches_per_epoch = self.towers[0].engine.batches_per_epoch
+        self._graph_keys = set()
+
+    # -- helpers --------------------------------------------------------------------------------------
+    def _on(self, t: int):
+        import contextlib
+
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.cuda.device(self.devices[t]))
+        stack.enter_context(torch.cuda.stream(self.streams[t]))
+        return stack
+
+    def synchronize(self):
+        for d in {d for d in self.devices if d.type == "cuda"}:
+            torch.cuda.synchronize(d)
+
+    def host_calls_per_chunk(self) -> int:
+        """Host calls per tower per chunk of steps in steady state (inside an epoch)."""
+        return 1 if (self._loop is None and self.use_graph) else 3 * self.chunk
+
+    def describe(self) -> str:
+        if self._loop is not None:
+            return self._loop.describe() + ", host loop (eager)"
+        where = "one GPU each" if len({d.index for d in self.devices}) == self.n else "sharing a GPU"
+        return (f"in-graph: 1 client, {self.n} towers ({where}), a stream and hipGraph chunks of {self.chunk} steps per "
+                f"tower, gradient mean inside the towers' backward launches (words stored into the other towers' "
+                f"inboxes through peer access), 2 launches/step, 1 host call per tower per chunk")
+
+    # -- capture: the towers' warm-up exchanges have to be in flight TOGETHER --------------------------
+    def _capture_all(self, pos: int, k: int, parity: int):
+        tw = self.towers
+        snaps = []
+        for t, tr in enumerate(tw):
+            with self._on(t):
+                snaps.append(tr._snapshot())
+                tr.engine.reset_step_workspace(parity)
+        for _ in range(2):                        # real exchanges among all towers, rolled back below
+            for t, tr in enumerate(tw):
+                with self._on(t):
+                    tr._one_step(pos)
+        self.synchronize()
+        for t, tr in enumerate(tw):
+            with self._on(t):
+                tr._restore(snaps[t])
+                tr.engine.reset_step_workspace(parity)
+        self.synchronize()
+        for t, tr in enumerate(tw):
+            with torch.cuda.device(self.devices[t]):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self.streams[t], capture_error_mode="thread_local"):
+                    for i in range(k):
+                        tr._one_step(pos + i)
+                tr.engine.parity = parity
+                tr._graphs[(pos, k, parity, tr._bound_set)] = graph
+        self._graph_keys.add((pos, k, parity))
+
+    def prepare(self, steps_hint=()):
+        """Capture every chunk graph the hinted ``run_steps`` calls will need."""
+        if self._loop is not None or not self.use_graph:
+            return
+        lead = self.towers[0]
+        cursor, parity = lead.engine._host_cursor, lead.engine.parity
+        live = parity
+        keys = []
+        for n in steps_hint:
+            for k in lead._schedule(cursor, n):
+                key = (cursor % self.batches_per_epoch, k, parity)
+                if key not in self._graph_keys and key not in keys:
+                    keys.append(key)
+                cursor += k
+                parity ^= k & 1
+        for pos, k, par in keys:
+            self._capture_all(pos, k, par)
+        for t, tr in enumerate(self.towers):
+            with self._on(t):
+                tr.engine.reset_step_workspace(live)
+        self.synchronize()
+
+    def run_steps(self, n: int):
+        if self._loop is not None:
+            return self._loop.run_steps(n)
+        lead = self.towers[0]
+        bpe = self.batches_per_epoch
+        for k in lead._schedule(lead.engine._host_cursor, n):
+            cur = lead.engine._host_cursor
+            if self.use_graph and (cur % bpe, k, lead.engine.parity) not in self._graph_keys:
+                self._capture_all(cur % bpe, k, lead.engine.parity)
+            for t, tr in enumerate(self.towers):
+                with self._on(t):
+                    tr.run_steps(k)               # one graph launch (plus the reshuffle at an epoch boundary)
+
+    # -- the trainer surface --------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.devices[0]
+
+    def last_loss(self) -> float:
+        if self._loop is not None:
+            return self._loop.last_loss()
+        self.synchronize()
+        return sum(tr.last_loss() for tr in self.towers) / self.n
+
+    def evaluate(self, x, y):
+        if self._loop is not None:
+            return self._loop.evaluate(x, y)
+        self.synchronize()
+        with torch.cuda.device(self.devices[0]):
+            return self.towers[0].evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        if self._loop is not None:
+            return self._loop.global_step_value()
+        self.synchronize()
+        return self.towers[0].global_step_value()
+
+    def replicas_identical(self) -> bool:
+        if self._loop is not None:
+            return self._loop.replicas_identical()
+        self.synchronize()
+        ref0 = self.towers[0].params.cpu()
+        return all(torch.equal(ref0, tr.params.cpu()) for tr in self.towers[1:])
+
+    def healthy(self) -> bool:
+        if self._loop is not None:
+            return True
+        self.synchronize()
+        return all(tr.healthy() for tr in self.towers)
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            self.synchronize()
+        except Exception:  # noqa: BLE001 — tearing down after a device error
+            pass
+        for t, tr in enumerate(self.towers):
+            with torch.cuda.device(self.devices[t]):
+                tr.close()
 
 
 class _null:

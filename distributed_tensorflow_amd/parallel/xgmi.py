@@ -57,9 +57,45 @@ def _open(handle: bytes) -> int:
     return int(out.value)
 
 
+def _encode(obj) -> bytes:
+    """JSON with byte strings as {"__b64__": ...}: what crosses the control store is data, never code."""
+    import base64
+    import json
+
+    def conv(o):
+        if isinstance(o, (bytes, bytearray)):
+            return {"__b64__": base64.b64encode(bytes(o)).decode("ascii")}
+        if isinstance(o, dict):
+            return {str(k): conv(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [conv(v) for v in o]
+        if o is None or isinstance(o, (bool, int, float, str)):
+            return o
+        raise TypeError(f"cannot send {type(o).__name__} through the control store")
+
+    return json.dumps(conv(obj)).encode("utf-8")
+
+
+def _decode(blob: bytes):
+    import base64
+    import json
+
+    def conv(o):
+        if isinstance(o, dict):
+            if set(o) == {"__b64__"}:
+                return base64.b64decode(o["__b64__"])
+            return {k: conv(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [conv(v) for v in o]
+        return o
+
+    return conv(json.loads(bytes(blob).decode("utf-8")))
+
+
 class StoreGroup:
     """``all_gather_object`` / ``barrier`` over a task server's control store, for processes that were started
-    the reference's way (``--job_name/--task_index``) and share no ``torch.distributed`` group."""
+    the reference's way (``--job_name/--task_index``) and share no ``torch.distributed`` group.  Objects travel
+    as JSON (byte strings base64-coded): a peer that can reach the store can hand over data, not code."""
 
     def __init__(self, client, name: str, rank: int, world: int, timeout: float = 120.0):
         self.client, self.name, self.rank, self.world, self.timeout = client, name, int(rank), int(world), timeout
@@ -67,13 +103,11 @@ class StoreGroup:
         self._nbar = 0
 
     def all_gather_object(self, out: list, obj) -> None:
-        import pickle
-
         self._round += 1
         base = f"__grp__/{self.name}/{self._round}/"
-        self.client.set(base + str(self.rank), pickle.dumps(obj))
+        self.client.set(base + str(self.rank), _encode(obj))
         for r in range(self.world):       # blobs written by the other tasks of this job
-            out[r] = pickle.loads(self.client.get(base + str(r), timeout=self.timeout))
+            out[r] = _decode(self.client.get(base + str(r), timeout=self.timeout))
 
     def barrier(self) -> None:
         self._nbar += 1
@@ -102,6 +136,28 @@ def _barrier(group) -> None:
         dist.barrier(group=group)
 
 
+def _agree(group, world: int, error: Optional[str], what: str) -> None:
+    """Collective go / no-go that doubles as a barrier: every rank reports whether its LOCAL part of a set-up
+    step worked, and every rank raises together when any of them failed.  A rank that raised on its own
+    (a refused mapping, an allocation that failed) would leave the others waiting in the next collective."""
+    if world <= 1:
+        if error:
+            raise RuntimeError(f"{what}: {error}")
+        return
+    seen = _all_gather(group, {"error": error}, world)
+    bad = [(r, s["error"]) for r, s in enumerate(seen) if s and s.get("error")]
+    if bad:
+        raise RuntimeError(f"{what} failed on rank(s) " + "; ".join(f"{r}: {e}" for r, e in bad))
+
+
+def _export_all(alloc) -> dict:
+    """Run ``alloc()`` (allocation + export, local work only) and return its dict, or {"error": ...}."""
+    try:
+        return alloc()
+    except Exception as e:  # noqa: BLE001 — reported to every rank by the caller
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 class XgmiExchange:
     """Buffers and peer mappings of one replica.
 
@@ -123,15 +179,23 @@ class XgmiExchange:
         self._max = lib.dtf_xgmi_max_ranks()
         self._closed = False
         self._mapped: List[int] = []
-        with torch.cuda.device(self.device):
-            slab_bytes = 2 * self.padded * 4
-            self._grad_ptr = _alloc(slab_bytes, uncached_grads)
-            self._flag_ptr = _alloc(4096, True)
-            self._grad_buf = _DeviceBuffer(self._grad_ptr, slab_bytes, "<f4", 4, True)
-            both = torch.as_tensor(self._grad_buf, device=self.device)
-            self.grads = [both[: self.padded][: self.numel], both[self.padded:][: self.numel]]
-            self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
-            self.state[0] = 1                                   # exchanges are numbered from 1; flags start at 0
+        self._grad_ptr = self._flag_ptr = 0
+        self._alloc_error: Optional[str] = None
+        self.grads = []
+        try:
+            with torch.cuda.device(self.device):
+                slab_bytes = 2 * self.padded * 4
+                self._grad_ptr = _alloc(slab_bytes, uncached_grads)
+                self._flag_ptr = _alloc(4096, True)
+                self._grad_buf = _DeviceBuffer(self._grad_ptr, slab_bytes, "<f4", 4, True)
+                both = torch.as_tensor(self._grad_buf, device=self.device)
+                self.grads = [both[: self.padded][: self.numel], both[self.padded:][: self.numel]]
+                self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+                self.state[0] = 1                               # exchanges are numbered from 1; flags start at 0
+        except Exception as e:  # noqa: BLE001 — with peers, the failure is announced to them in connect()
+            self._alloc_error = f"{type(e).__name__}: {e}"
+            if not connect or self.world == 1:
+                raise
         self._peer_grad = [0] * self.world
         self._peer_flag = [0] * self.world
         self._peer_grad[self.rank], self._peer_flag[self.rank] = self._grad_ptr, self._flag_ptr
@@ -144,28 +208,34 @@ class XgmiExchange:
                 "padded": self.padded}
 
     def connect(self, group=None):
-        """Swap IPC handles over ``group`` and map every peer's buffers."""
+        """Swap IPC handles over ``group`` and map every peer's buffers.  Every step that can fail on one rank
+        only (allocation, export, opening a handle) is followed by a collective verdict, so that the ranks
+        either all go on or all raise."""
         if self.world > 1:
-            import torch.distributed as dist
-
-            mine = self.handles()
-            everyone: List[Optional[dict]] = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            with torch.cuda.device(self.device):
-                for h in everyone:
-                    r = h["rank"]
-                    if r == self.rank:
-                        continue
-                    if h["padded"] != self.padded:
-                        raise RuntimeError("replicas disagree on the slab size")
-                    self._peer_grad[r] = _open(h["grad"])
-                    self._peer_flag[r] = _open(h["flag"])
-                    self._mapped += [self._peer_grad[r], self._peer_flag[r]]
+            mine = {"error": self._alloc_error} if self._alloc_error else _export_all(self.handles)
+            everyone = _all_gather(group, mine, self.world)
+            bad = [(r, h["error"]) for r, h in enumerate(everyone) if h.get("error")]
+            if bad:
+                raise RuntimeError("peer-mapped exchange: allocation / export failed on rank(s) "
+                                   + "; ".join(f"{r}: {e}" for r, e in bad))
+            error = None
+            try:
+                with torch.cuda.device(self.device):
+                    for h in everyone:
+                        r = h["rank"]
+                        if r == self.rank:
+                            continue
+                        if h["padded"] != self.padded:
+                            raise RuntimeError("replicas disagree on the slab size")
+                        self._peer_grad[r] = _open(h["grad"])
+                        self._mapped.append(self._peer_grad[r])
+                        self._peer_flag[r] = _open(h["flag"])
+                        self._mapped.append(self._peer_flag[r])
+            except Exception as e:  # noqa: BLE001
+                error = f"{type(e).__name__}: {e}"
+            # (also the barrier: nobody announces into a flag array that is not mapped yet)
+            _agree(group, self.world, error, "peer-mapped exchange: mapping the peers' buffers")
         self._write_table()
-        if self.world > 1:
-            import torch.distributed as dist
-
-            dist.barrier(group=group)     # nobody announces into a flag array that is not mapped yet
 
     def connect_local(self, peers: List["XgmiExchange"]):
         """Replicas that live in ONE process (tests, in-graph towers on one GPU): plain pointers."""
@@ -255,26 +325,42 @@ class PeerShards:
 
             uncached = os.environ.get("DTF_SHARDS_UNCACHED", "1") != "0"
         self.uncached = bool(uncached)
-        with torch.cuda.device(self.device):
-            self._ptr = _alloc(self.total * 4, self.uncached)
-            self._buf = _DeviceBuffer(self._ptr, self.total * 4, "<f4", 4, True)
-            self.buffer = torch.as_tensor(self._buf, device=self.device)
+        self._ptr = 0
+        self.buffer = None
+
+        def local():
+            with torch.cuda.device(self.device):
+                self._ptr = _alloc(self.total * 4, self.uncached)
+                self._buf = _DeviceBuffer(self._ptr, self.total * 4, "<f4", 4, True)
+                self.buffer = torch.as_tensor(self._buf, device=self.device)
+                return {"rank": self.rank, "total": self.total,
+                        "handle": _export(self._ptr) if self.world > 1 else b""}
+
+        mine = _export_all(local)
+        if self.world == 1 and mine.get("error"):
+            raise RuntimeError(mine["error"])
         ptrs = [0] * self.world
         ptrs[self.rank] = self._ptr
         if self.world > 1:
-            import torch.distributed as dist
-
-            everyone: List[Optional[dict]] = [None] * self.world
-            dist.all_gather_object(everyone, {"rank": self.rank, "handle": _export(self._ptr), "total": self.total},
-                                   group=group)
-            with torch.cuda.device(self.device):
-                for h in everyone:
-                    if h["rank"] == self.rank:
-                        continue
-                    if h["total"] != self.total:
-                        raise RuntimeError("workers disagree on the slab size")
-                    ptrs[h["rank"]] = _open(h["handle"])
-                    self._mapped.append(ptrs[h["rank"]])
+            # every local step that may fail is followed by a verdict of ALL ranks (see _agree)
+            everyone = _all_gather(group, mine, self.world)
+            bad = [(r, h["error"]) for r, h in enumerate(everyone) if h.get("error")]
+            if bad:
+                raise RuntimeError("peer-mapped shards: allocation / export failed on rank(s) "
+                                   + "; ".join(f"{r}: {e}" for r, e in bad))
+            error = None
+            try:
+                with torch.cuda.device(self.device):
+                    for h in everyone:
+                        if h["rank"] == self.rank:
+                            continue
+                        if h["total"] != self.total:
+                            raise RuntimeError("workers disagree on the slab size")
+                        ptrs[h["rank"]] = _open(h["handle"])
+                        self._mapped.append(ptrs[h["rank"]])
+            except Exception as e:  # noqa: BLE001
+                error = f"{type(e).__name__}: {e}"
+            _agree(group, self.world, error, "peer-mapped shards: mapping the peers' buffers")
         self._tab = (C.c_uint64 * self.world)(*ptrs)
         self._group = group
 
@@ -288,9 +374,7 @@ class PeerShards:
         self.my_shard.copy_(slab[a:a + self.chunk])
         torch.cuda.synchronize(self.device)
         if self.world > 1:
-            import torch.distributed as dist
-
-            dist.barrier(group=self._group)
+            _barrier(self._group)
 
     def pull(self, local: torch.Tensor):
         if local.numel() != self.total:
@@ -352,7 +436,7 @@ class PeerInbox:
     """
 
     def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None, timeout_ms: int = 5000,
-                 compact: bool = False):
+                 compact: bool = False, connect: bool = True):
         lib = hb.require()
         if not 1 <= world <= lib.dtf_xgmi_max_ranks():
             raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
@@ -364,27 +448,52 @@ class PeerInbox:
         self.slot_bytes = self.world * self.numel * (4 if self.compact else 8)
         self._closed = False
         self._mapped: List[int] = []
-        with torch.cuda.device(self.device):
-            self._ptr = _alloc(2 * self.slot_bytes, True)
-            if self.compact:
-                hb._check(lib.dtf_xgmi_fill(self._ptr, 0xFF, 2 * self.slot_bytes), "dtf_xgmi_fill")
-            # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and an
-            # empty inbox, all zeros, never matches), [2]: error
-            self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._ptr = 0
+
+        def local():
+            with torch.cuda.device(self.device):
+                self._ptr = _alloc(2 * self.slot_bytes, True)
+                if self.compact:
+                    hb._check(lib.dtf_xgmi_fill(self._ptr, 0xFF, 2 * self.slot_bytes), "dtf_xgmi_fill")
+                # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and
+                # an empty inbox, all zeros, never matches), [2]: error
+                self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+                return {"rank": self.rank, "bytes": self.slot_bytes,       # (differs if `compact` does)
+                        "handle": _export(self._ptr) if (self.world > 1 and connect) else b""}
+
+        mine = _export_all(local)
+        if (self.world == 1 or not connect) and mine.get("error"):
+            raise RuntimeError(mine["error"])
         self._ptrs = [0] * self.world
         self._ptrs[self.rank] = self._ptr
-        if self.world > 1:
-            everyone = _all_gather(group, {"rank": self.rank, "handle": _export(self._ptr),
-                                           "bytes": self.slot_bytes}, self.world)   # (differs if `compact` does)
-            with torch.cuda.device(self.device):
-                for h in everyone:
-                    if h["rank"] == self.rank:
-                        continue
-                    if h["bytes"] != self.slot_bytes:
-                        raise RuntimeError("replicas disagree on the inbox size")
-                    self._ptrs[h["rank"]] = _open(h["handle"])
-                    self._mapped.append(self._ptrs[h["rank"]])
-            _barrier(group)                            # nobody writes into an inbox that is not mapped yet
+        if self.world > 1 and connect:
+            everyone = _all_gather(group, mine, self.world)
+            bad = [(r, h["error"]) for r, h in enumerate(everyone) if h.get("error")]
+            if bad:
+                raise RuntimeError("peer inboxes: allocation / export failed on rank(s) "
+                                   + "; ".join(f"{r}: {e}" for r, e in bad))
+            error = None
+            try:
+                with torch.cuda.device(self.device):
+                    for h in everyone:
+                        if h["rank"] == self.rank:
+                            continue
+                        if h["bytes"] != self.slot_bytes:
+                            raise RuntimeError("replicas disagree on the inbox size")
+                        self._ptrs[h["rank"]] = _open(h["handle"])
+                        self._mapped.append(self._ptrs[h["rank"]])
+            except Exception as e:  # noqa: BLE001
+                error = f"{type(e).__name__}: {e}"
+            # (also the barrier: nobody writes into an inbox that is not mapped yet)
+            _agree(group, self.world, error, "peer inboxes: mapping the peers' buffers")
+
+    def connect_local(self, peers: List["PeerInbox"]):
+        """Replicas that live in ONE process (in-graph towers): the peers' inboxes are plain pointers.  Towers
+        on different GPUs need peer access between the devices (``hb.enable_peer_access``) first."""
+        for p in peers:
+            if p.slot_bytes != self.slot_bytes or p.world != self.world:
+                raise ValueError("towers disagree on the inbox size")
+            self._ptrs[p.rank] = p._ptr
 
     def step_descriptor(self, offsets: dict) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_xg``; ``offsets`` maps W1 / b1 / W2 / b2 to the element offsets of their

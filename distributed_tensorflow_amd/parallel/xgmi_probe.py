@@ -32,7 +32,11 @@ def main(argv=None) -> int:
     ap.add_argument("--chunk", type=int, default=50)
     ap.add_argument("--rows", type=int, default=5500)
     ap.add_argument("--uncached", type=int, default=0)
+    ap.add_argument("--budget", type=float, default=0.0,
+                    help="seconds after which no further stage is started (0: no limit); rank 0's clock decides")
+    ap.add_argument("--only", default="", help="run just this stage (xgmi)")
     args = ap.parse_args(argv)
+    t_start = time.monotonic()
 
     import torch
     import torch.distributed as dist
@@ -44,6 +48,16 @@ def main(argv=None) -> int:
 
     def note(msg):
         print(f"[peer-exchange trial {args.rank}/{args.world}] {msg}", file=sys.stderr, flush=True)
+
+    def go_on(stage: str) -> bool:
+        """Collective: start another stage only while rank 0 is inside the budget (and the stage is wanted)."""
+        if args.only:
+            return False
+        flag = torch.tensor([1 if (args.budget <= 0 or time.monotonic() - t_start < args.budget) else 0])
+        dist.broadcast(flag, src=0)
+        if not int(flag.item()):
+            out.setdefault("skipped", []).append(stage)
+        return bool(int(flag.item()))
 
     try:
         dist.init_process_group("gloo", rank=args.rank, world_size=args.world,
@@ -87,6 +101,8 @@ def main(argv=None) -> int:
         # the exchange inside the backward launch (2 launches per step), with 8-byte {number, value} words and with
         # bare 4-byte values (half the bytes on a link), each judged by the same criteria
         for mode2, tag in (("xgmi2", "2"), ("xgmi2c", "2c")):
+            if not go_on(mode2):
+                continue
             try:
                 t2 = build_replica_trainer(mode2, device=dev, dataset=ds, batch=100, lr=0.001, seed=1, rank=args.rank,
                                            world=args.world, chunk=args.chunk, use_graph=True, timeout_ms=10000)
@@ -121,6 +137,8 @@ def main(argv=None) -> int:
         # is the one reported
         forms = {}
         for fused_push in (True, False):
+            if not go_on("async, push " + ("in the backward" if fused_push else "as a launch")):
+                continue
             ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
                                        rank=args.rank, world=args.world, chunk=args.chunk, use_graph=True,
                                        fused_push=fused_push)
@@ -148,10 +166,11 @@ def main(argv=None) -> int:
                  f"ok={forms[fused_push]['async_ok']} {forms[fused_push]['async_ms_per_step']} ms/step")
             dist.barrier()
             ta.close()
-        good = [f for f in forms.values() if f["async_ok"]] or list(forms.values())
-        out.update(min(good, key=lambda f: f["async_ms_per_step"]))
-        out["async_ms_per_step_by_push"] = {("in_backward" if k else "own_launch"): v["async_ms_per_step"]
-                                            for k, v in forms.items()}
+        if forms:
+            good = [f for f in forms.values() if f["async_ok"]] or list(forms.values())
+            out.update(min(good, key=lambda f: f["async_ms_per_step"]))
+            out["async_ms_per_step_by_push"] = {("in_backward" if k else "own_launch"): v["async_ms_per_step"]
+                                                for k, v in forms.items()}
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer: "do not use this path here"
         out["error"] = f"{type(e).__name__}: {e}"

@@ -28,6 +28,7 @@ def main():
                                world=world, chunk=4, use_graph=use_graph)
     tr.prepare(steps_hint=(13,))
     tr.run_steps(13)          # crosses an epoch boundary (11 batches per epoch)
+    global_step = tr.global_step_value()      # (a collective for the point-to-point transport: every rank calls it)
     params = tr.params.clone()
     gathered = [torch.zeros_like(params) for _ in range(world)]
     dist.all_gather(gathered, params)
@@ -36,7 +37,7 @@ def main():
     loss, acc = tr.evaluate(tx, ty)
     if rank == 0:
         print("RESULT " + json.dumps({"mode": mode, "world": world, "replicas_identical": same,
-                                      "global_step": tr.global_step_value(), "loss": loss, "acc": acc,
+                                      "global_step": global_step, "served": getattr(tr, "served", None), "loss": loss, "acc": acc,
                                       "checksum": float(params.double().sum()), "desc": tr.describe()}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

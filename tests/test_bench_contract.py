@@ -29,6 +29,9 @@ def test_single_process_defaults_to_one_gpu_and_reports_the_contract_fields():
     assert r["config"]["global_batch"] == 100 and r["scaling"] == "weak" and r["dtype"] == "fp32"
     assert r["value"] == pytest.approx(100 * 30 / (r["ms_per_step"] * 30 / 1000.0), rel=1e-3)
     assert r["global_step"] == 35                     # every timed and warm-up step applied its update
+    assert r["ranks_seen"] == 1 and r["generic_steps"] == 0 and r["multi_gpu_measured"] is False
+    # the reference's "Total Time" epoch is measured whatever --steps says (55 batches in the CPU-sized set)
+    assert r["sec_per_epoch"] > 0 and r["steps_per_epoch"] == 55 and "upload_and_first_shuffle_s" in r["setup_s"]
 
 
 @pytest.mark.parametrize("mode", [None, "async"])
@@ -42,17 +45,34 @@ def test_two_ranks_over_gloo_report_the_aggregate(mode):
     r = _json_line(p.stdout)
     assert FIELDS <= set(r) and r["n_gpus"] == 2 and r["config"]["global_batch"] == 200
     assert r["value"] == pytest.approx(2 * 100 * 20 / (r["ms_per_step"] * 20 / 1000.0), rel=1e-3)
-    if mode is None:      # auto: both synchronous exchanges were probed and one was kept
-        assert set(r["mode_probe_ms_per_step"]) == {"sync", "towers"}
-        assert r["global_step"] == 24 + 200           # one update per round of two worker batches (+ probe rounds)
-    else:                 # async rule: every worker's gradient is its own update
-        assert r["global_step"] == 2 * 24
+    assert r["ranks_seen"] == 2 and r["sec_per_epoch"] > 0
+    if mode is None:      # auto: both synchronous exchanges ran the same measurement and one was kept
+        assert set(r["mode_ms_per_step"]) == {"sync", "towers"}
+        assert r["ms_per_step"] == min(r["mode_ms_per_step"].values())
+        assert r["global_step"] == 24                 # one update per round of two worker batches
+        a = r["async_mode"]                           # and the asynchronous mode next to it, on the same data set
+        assert a["global_step"] == 2 * (a["steps"] + a["warmup"]) and a["every_push_counted"] is True
+        assert "send/recv" in a["parallelism"] and a["value"] > 0
+    else:                 # asynchronous parameter servers: every worker's gradient is its own update
+        assert r["global_step"] == 2 * 24 and "send/recv" in r["config"]["parallelism"]
+
+
+def test_plain_invocation_with_several_gpus_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed.run): the launcher creates the rank processes itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu", "--steps", "20",
+                        "--warmup", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = _json_line(p.stdout)
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["config"]["global_batch"] == 200
+    assert r["sec_per_epoch"] > 0 and r["async_mode"]["value"] > 0 and r["value"] > 0
 
 
 def test_gpus_flag_must_match_the_world_size():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu", "--steps", "2"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=120)
-    assert p.returncode != 0 and "torch.distributed.run" in (p.stderr + p.stdout)
+                       cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "one process per GPU" in (p.stderr + p.stdout)
 
 
 @pytest.mark.gpu
@@ -70,10 +90,13 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     doc = json.loads([line for line in p.stdout.splitlines() if line.startswith("{")][-1])
     assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 200
     assert doc["peer_exchange_trial"]["ok"] is True and doc["peer_exchange_trial"]["identical"] is True
-    assert set(doc["mode_probe_ms_per_step"]) == {"xgmi", "xgmi2", "xgmi2c"}
+    assert set(doc["mode_ms_per_step"]) == {"xgmi", "xgmi2", "xgmi2c"} and doc["ranks_seen"] == 2
     assert doc["peer_exchange_trial"]["ok2"] is True and doc["peer_exchange_trial"]["ok2c"] is True
     assert "peer-mapped" in doc["config"]["parallelism"]          # whichever of the two exchanges was faster
-    assert doc["global_step"] >= 700
+    assert doc["global_step"] == 700 and doc["sec_per_epoch"] > 0 and doc["multi_gpu_measured"] is False
     a = doc["async_mode"]                                   # the asynchronous workers, measured next to it
-    assert a["every_push_counted"] is True and a["global_step"] == 2 * 2 * a["steps"] and a["value"] > 0
-    assert "one-sided" in a["parallelism"] and doc["peer_exchange_trial"]["async_ok"] is True
+    assert a["every_push_counted"] is True and a["global_step"] == 2 * (a["steps"] + a["warmup"]) and a["value"] > 0
+    assert doc["peer_exchange_trial"]["async_ok"] is True
+    assert set(doc["async_modes"]) == {"xgmi_async", "async_rccl"} and "one-sided" in doc["async_modes"]["xgmi_async"]["parallelism"]
+    ig = doc["ingraph_mode"]                                # one client, towers sharing the GPU in this rehearsal
+    assert ig["replicas_identical"] is True and ig["healthy"] is True and ig["host_calls_per_tower_per_chunk"] == 1

@@ -34,8 +34,17 @@ def test_sync_shards_and_towers_agree_and_replicas_stay_identical():
 
 @pytest.mark.slow
 def test_async_rule_counts_every_worker_gradient():
-    res = _run("async")
+    res = _run("async_lockstep")
     assert res["replicas_identical"] and res["global_step"] == 26           # N updates per round
+
+
+def test_async_send_recv_parameter_servers_count_every_push():
+    """Two-sided asynchronous PS (gloo here, RCCL on GPUs): one communicator + service lane per (worker, shard)
+    pair; every worker gradient is one update of every shard, global_step == sum of the workers' pushes."""
+    res = _run("async_rccl")
+    assert res["global_step"] == 26 and res["served"] == 26     # 13 own + 13 served for the peer, on every rank
+    assert res["replicas_identical"]                            # after the final refresh from the shards
+    assert "send/recv" in res["desc"] and res["loss"] == res["loss"]
 
 
 def test_in_graph_towers_mean_gradient_and_identical_replicas():

@@ -71,7 +71,7 @@ def test_ps_session_on_gpu_worker_with_host_shards():
             s.stop()
 
 
-@pytest.mark.parametrize("mode", ["sync", "towers", "async"])
+@pytest.mark.parametrize("mode", ["sync", "towers", "async_lockstep"])
 def test_rccl_world_of_one_with_graph_capture(mode):
     """The collective step (kernels + RCCL calls + sharded SGD) captured into hipGraphs; world size 1."""
     port = free_ports(1)[0]
