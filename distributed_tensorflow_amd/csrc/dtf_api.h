@@ -110,6 +110,13 @@ int dtf_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, flo
 int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int cols,
                     void* stream);
 
+// Epoch refresh in one launch (gram.hip): dst[r] = src[perm[r]] for r < nb * B (dst may be null) and
+// gram[j][m][i] = 1 + x_{j+1}[m] . x_j[i] over the epoch-ordered rows (zero for B <= i < ld), fp32 MFMA.
+int dtf_gather_gram_supported(int B, int K);
+// ysrc / ydst (both or neither): labels [rows][C] gathered alike.
+int dtf_gather_gram(const float* src, const int64_t* perm, float* dst, float* gram, int rows_src, int B, int K,
+                    int nb, int ld, const float* ysrc, float* ydst, int C, void* stream);
+
 // --- one-shot gradient all-reduce + SGD apply over peer-mapped HBM (xgmi.hip) -----------------
 #define DTF_XGMI_MAX_RANKS 16
 int dtf_xgmi_max_ranks(void);

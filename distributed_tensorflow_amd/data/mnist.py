@@ -277,14 +277,40 @@ class DeviceDataset:
         perm = self._take_perm()
         if self.device.type == "cuda":
             from ..ops import hip_backend as hb
-            hb.gather_rows(self.x, perm, s["x"])
-            hb.gather_rows(self.y, perm, s["y"])
+            nb, b = self.batches_per_epoch, self.batch_size
+            if self._with_gram and nb >= 2 and self._fused_refresh():
+                # ONE launch: the rows a workgroup loads for the Gram products are the rows it stores in epoch order
+                self._alloc_gram(s)
+                hb.gather_gram(self.x, perm, s["x"], s["gram"], b, nb, self.y, s["y"])
+                if nb * b < self.num_examples:       # rows beyond the last whole mini-batch (never trained on)
+                    hb.gather_rows(self.x, perm[nb * b:], s["x"][nb * b:])
+                    hb.gather_rows(self.y, perm[nb * b:], s["y"][nb * b:])
+            else:
+                hb.gather_rows(self.x, perm, s["x"])
+                if self._with_gram:
+                    self._fill_gram(s)
+                hb.gather_rows(self.y, perm, s["y"])
         else:
             torch.index_select(self.x, 0, perm, out=s["x"])
             torch.index_select(self.y, 0, perm, out=s["y"])
-        if self._with_gram:
-            self._fill_gram(s)
+            if self._with_gram:
+                self._fill_gram(s)
         self._stage_perm()          # next epoch's order: host work and copy happen behind the queued GPU work
+
+    def _fused_refresh(self) -> bool:
+        """Whether the hand-written gather + Gram kernel (csrc/gram.hip) covers this set's shape."""
+        if self.device.type != "cuda" or os.environ.get("DTF_GRAM_KERNEL", "1") == "0":
+            return False
+        from ..ops import hip_backend as hb
+
+        return (hb.gather_gram_supported(self.batch_size, self.x.shape[1])
+                and self.num_examples * self.x.shape[1] * 4 < 2 ** 32)
+
+    def _alloc_gram(self, s):
+        nb, b = self.batches_per_epoch, self.batch_size
+        if s["gram"] is None:
+            ld = (b + 15) // 16 * 16
+            s["gram"] = torch.zeros((nb - 1, b, ld), dtype=torch.float32, device=self.device)
 
     def _take_perm(self) -> torch.Tensor:
         """The permutation of this epoch, already on the device: it is drawn and copied (pinned, asynchronous)
@@ -316,12 +342,19 @@ class DeviceDataset:
         self._pin_copied[turn].record(torch.cuda.current_stream(self.device))
 
     def _fill_gram(self, s):
+        """Gram blocks of the epoch order already in ``s["x"]``."""
         nb, b = self.batches_per_epoch, self.batch_size
         if nb < 2:
             return
-        if s["gram"] is None:
-            ld = (b + 15) // 16 * 16
-            s["gram"] = torch.zeros((nb - 1, b, ld), dtype=torch.float32, device=self.device)
+        self._alloc_gram(s)
+        if self._fused_refresh():
+            from ..ops import hip_backend as hb
+
+            if getattr(self, "_identity", None) is None:
+                self._identity = torch.arange(self.num_examples, dtype=torch.int64, device=self.device)
+            hb.gather_gram(s["x"], self._identity, None, s["gram"], b, nb)       # no row is stored: Gram only
+            return
+        if s["tmp"] is None:       # library fallback (shapes the kernel does not cover, CPU): batched GEMM + copy
             s["tmp"] = torch.empty((nb - 1, b, b), dtype=torch.float32, device=self.device)
         xb = s["x"][:nb * b].view(nb, b, -1)
         # fp32 matrix units (no reduced-precision shortcut): the block enters the forward pass exactly

@@ -113,6 +113,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_philox_normal.argtypes = [vp, i64, u64, u64, f32, f32, vp]
     lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
     lib.dtf_hip_build_info.restype = C.c_char_p
+    lib.dtf_gather_gram_supported.argtypes = [i32, i32]
+    lib.dtf_gather_gram_supported.restype = C.c_int
+    lib.dtf_gather_gram.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.dtf_gather_gram.restype = C.c_int
     lib.dtf_xgmi_max_ranks.argtypes = []
     lib.dtf_xgmi_alloc.argtypes = [C.POINTER(C.c_void_p), i64, i32]
     lib.dtf_xgmi_free.argtypes = [vp]
@@ -332,6 +336,36 @@ def gather_rows(src, idx, out: Optional[torch.Tensor] = None):
         raise HipKernelError("gather_rows: bad output shape")
     _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, _stream()), "dtf_gather_rows")
     return out
+
+
+def gather_gram_supported(B: int, K: int) -> bool:
+    return bool(require().dtf_gather_gram_supported(int(B), int(K)))
+
+
+def gather_gram(src, perm, dst, gram, B: int, nb: int, ysrc=None, ydst=None):
+    """Epoch refresh in ONE launch: ``dst[r] = src[perm[r]]`` for r < nb * B (``dst`` None: not stored),
+    ``gram[j, m, i] = 1 + x_{j+1}[m] . x_j[i]`` over the epoch-ordered rows and, with ``ysrc`` / ``ydst``, the
+    labels ``ydst[r] = ysrc[perm[r]]`` (csrc/gram.hip)."""
+    lib = require()
+    _f32c(src, "src"), _f32c(gram, "gram")
+    if dst is not None:
+        _f32c(dst, "dst")
+    if perm.dtype != torch.int64 or not perm.is_cuda or not perm.is_contiguous() or perm.numel() < nb * B:
+        raise HipKernelError("gather_gram: perm must be a contiguous int64 CUDA tensor of at least nb * B entries")
+    K = src.shape[1]
+    if gram.dim() != 3 or gram.shape[0] < nb - 1 or gram.shape[1] != B or (dst is not None and (
+            dst.shape[1] != K or dst.shape[0] < nb * B)):
+        raise HipKernelError("gather_gram: shape mismatch")
+    C_ = 0
+    if ydst is not None:
+        _f32c(ysrc, "ysrc"), _f32c(ydst, "ydst")
+        C_ = ysrc.shape[1]
+        if ysrc.shape[0] != src.shape[0] or ydst.shape[1] != C_ or ydst.shape[0] < nb * B:
+            raise HipKernelError("gather_gram: label shape mismatch")
+    _check(lib.dtf_gather_gram(_ptr(src), _ptr(perm), _ptr(dst), _ptr(gram), src.shape[0], int(B), K, int(nb),
+                               gram.shape[2], _ptr(ysrc) if ydst is not None else None, _ptr(ydst), C_, _stream()),
+           "dtf_gather_gram")
+    return gram
 
 
 def mlp_eval(x, y, W1, b1, W2, b2, act: int, a2_ws, loss_sum, correct):

@@ -251,3 +251,85 @@ def test_pipelined_graphs_can_be_replayed_in_any_order(n):
         for k in MLPEngine.PARAM_NAMES:
             torch.testing.assert_close(g.p[k], e.p[k], rtol=1e-5, atol=1e-6)
             g.p[k].copy_(e.p[k])
+
+
+@pytest.mark.parametrize("rows,B,K", [(55000, 100, 784), (1234, 100, 784), (700, 100, 100), (450, 33, 20), (260, 104, 64)])
+def test_gather_gram_matches_gather_then_batched_matmul(rows, B, K):
+    """csrc/gram.hip: epoch-ordered copy + Gram blocks of consecutive mini-batches in one launch, against
+    index_select and a float64 batched product (and, at the training shape, torch.baddbmm in fp32)."""
+    g = torch.Generator().manual_seed(11)
+    src = torch.rand(rows, K, generator=g).to(DEV)
+    perm = torch.randperm(rows, generator=g).to(DEV)
+    nb = rows // B
+    ld = (B + 15) // 16 * 16
+    dst = torch.full((rows, K), -7.0, device=DEV)
+    gram = torch.full((nb - 1, B, ld), -7.0, device=DEV)
+    assert hb.gather_gram_supported(B, K)
+    ysrc = torch.rand(rows, 10, generator=g).to(DEV)
+    ydst = torch.full((rows, 10), -7.0, device=DEV)
+    hb.gather_gram(src, perm, dst, gram, B, nb, ysrc, ydst)
+    assert torch.equal(ydst[:nb * B], ysrc[perm[:nb * B]]) and bool((ydst[nb * B:] == -7.0).all())
+    want_rows = src[perm[:nb * B]]
+    assert torch.equal(dst[:nb * B], want_rows)                       # a gather moves bits
+    assert bool((dst[nb * B:] == -7.0).all())                         # rows beyond the last whole batch: untouched
+    xb = want_rows.view(nb, B, K).double()
+    want = 1.0 + torch.bmm(xb[1:], xb[:-1].transpose(1, 2))
+    torch.testing.assert_close(gram[:, :, :B], want.float(), rtol=1e-5, atol=1e-5)
+    assert bool((gram[:, :, B:] == 0).all())
+    if (rows, B, K) == (55000, 100, 784):
+        lib = torch.baddbmm(torch.ones(1, 1, 1, device=DEV), xb[1:].float(), xb[:-1].float().transpose(1, 2))
+        torch.testing.assert_close(gram[:, :, :B], lib, rtol=1e-5, atol=1e-5)
+    # Gram blocks only (no copy), from an already ordered set
+    gram2 = torch.zeros_like(gram)
+    ident = torch.arange(rows, device=DEV)
+    hb.gather_gram(dst, ident, None, gram2, B, nb)
+    assert torch.equal(gram2, gram)
+
+
+def test_device_dataset_refresh_uses_the_fused_kernel_and_matches_the_library_path(monkeypatch):
+    from distributed_tensorflow_amd.data import DeviceDataset
+
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.rand(1230, 784, generator=g), torch.eye(10)[torch.randint(0, 10, (1230,), generator=g)]
+    a = DeviceDataset(x, y, DEV, 100, seed=3)
+    a.enable_pair_gram()
+    a.shuffle_epoch()
+    monkeypatch.setenv("DTF_GRAM_KERNEL", "0")
+    b = DeviceDataset(x, y, DEV, 100, seed=3)
+    b.enable_pair_gram()
+    b.shuffle_epoch()
+    assert a._fused_refresh() is False       # (the variable is read per call)
+    assert torch.equal(a.x_epoch, b.x_epoch) and torch.equal(a.y_epoch, b.y_epoch)
+    torch.testing.assert_close(a.gram, b.gram, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,count", [(79516, 1), (79516, 2), (79516, 8), (1003, 3), (5, 16)])
+def test_sum_apply_is_n_mailboxes_in_one_launch(n, count):
+    p = _rand(n, seed=20)
+    gs = [_rand(n, seed=21 + i) for i in range(count)]
+    lr = torch.tensor([0.05], device=DEV)
+    step = torch.zeros(1, device=DEV)
+    want = p.double()
+    total = torch.zeros(n, dtype=torch.float32, device=DEV)
+    for gi in gs:
+        total = total + gi                       # index order, fp32: what the kernel does
+    want = (p - (0.05 * 0.5) * total)
+    hb.sum_apply_(p, gs, lr, scale=0.5, global_step=step)
+    torch.testing.assert_close(p, want, rtol=1e-6, atol=1e-6)
+    assert float(step) == 1.0
+
+
+def test_sgd_apply_atomic_loses_no_update_under_concurrent_streams():
+    n = 79516
+    p = torch.zeros(n, device=DEV)
+    g = torch.ones(n, device=DEV)
+    lr = torch.tensor([1.0], device=DEV)
+    step = torch.zeros(1, device=DEV)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(25):
+        for s in streams:
+            with torch.cuda.stream(s):
+                hb.sgd_apply_atomic_(p, g, lr, 1.0, step)
+    torch.cuda.synchronize()
+    assert float(p.min()) == float(p.max()) == -100.0 and float(step) == 100.0
