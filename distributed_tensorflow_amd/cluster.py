@@ -112,6 +112,28 @@ def lookup_server(target: str) -> Optional["Server"]:
     return _SERVERS.get(target)
 
 
+def _bind_address(host: str) -> str:
+    """Interface the task server listens on: the one the cluster spec names.  ``localhost`` clusters (every test,
+    every one-node run) stay on the loopback interface; a name or address of this machine binds that address only;
+    anything that cannot be bound here falls back to all interfaces (``DTF_BIND_ADDRESS`` overrides).  The server
+    has no authentication: it belongs on a loopback or a trusted cluster network."""
+    import os
+    import socket
+
+    forced = os.environ.get("DTF_BIND_ADDRESS")
+    if forced:
+        return forced
+    if host in ("localhost", "127.0.0.1", "", "::1"):
+        return "127.0.0.1"
+    try:
+        ip = socket.gethostbyname(host)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as probe:
+            probe.bind((ip, 0))              # only an address of this machine can be bound
+        return ip
+    except OSError:
+        return "0.0.0.0"
+
+
 class Server:
     def __init__(self, server_or_cluster_def, job_name: Optional[str] = None, task_index: Optional[int] = None,
                  protocol: Optional[str] = None, config: Optional[ConfigProto] = None, start: bool = True):
@@ -134,7 +156,7 @@ class Server:
     # -- lifecycle -------------------------------------------------------------
     def start(self):
         if self._native is None:
-            self._native = rt.TaskServer("0.0.0.0", self.port)
+            self._native = rt.TaskServer(_bind_address(self.host), self.port)
             _SERVERS[self.target] = self
             if self.config.log_device_placement:
                 print(f"[server] /job:{self.job_name}/task:{self.task_index} listening on :{self.port} "

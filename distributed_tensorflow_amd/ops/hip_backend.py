@@ -156,15 +156,21 @@ def load(required: bool = False) -> Optional[C.CDLL]:
         return _lib
     if _load_error is None:
         try:
-            if not _LIB_PATH.exists():
-                try:   # first use in a fresh checkout: build in-tree (hipcc cross-compiles, no GPU needed)
-                    from .. import build as _build
+            if "DTF_HIP_LIB" not in os.environ:
+                try:   # a no-op when the stamp matches the sources; builds in-tree otherwise (fresh checkout, stale
+                    from .. import build as _build      # library; hipcc cross-compiles, no GPU needed)
 
                     _build.build_hip()
                 except Exception as e:  # noqa: BLE001
-                    raise OSError(f"{_LIB_PATH} not built and the in-tree build failed: {e}") from None
+                    if not _LIB_PATH.exists():
+                        raise OSError(f"{_LIB_PATH} not built and the in-tree build failed: {e}") from None
             lib = C.CDLL(str(_LIB_PATH), mode=C.RTLD_GLOBAL)
-            _declare(lib)
+            try:
+                _declare(lib)
+                lib.dtf_abi_sizeof.argtypes = [C.c_int]
+            except AttributeError as e:     # a library older than this binding lacks a symbol
+                raise OSError(f"{_LIB_PATH} was built from other sources ({e}); rebuild with "
+                              f"python -m distributed_tensorflow_amd.build") from None
             # the ctypes mirrors must have the library's layout: a stale .so next to newer Python (or the reverse)
             # would otherwise read descriptor fields at the wrong offsets
             lib.dtf_abi_sizeof.argtypes = [C.c_int]

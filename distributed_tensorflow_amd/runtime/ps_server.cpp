@@ -39,6 +39,8 @@
 #include <memory>
 #include <list>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -206,16 +208,27 @@ bool wait_until(Server* s, Entry& e, std::unique_lock<std::mutex>& lk, int64_t t
   return true;
 }
 
+constexpr uint64_t kMaxBlobBytes = 64ull << 20;      // control-plane blobs: keys, handles, queue items
+constexpr uint64_t kMaxBufFloats = 1ull << 28;       // parameter / accumulator buffers: 1 GiB of floats
+
 void serve_connection(Server* s, Server::Conn* self) {
   const int fd = self->fd;
   int one = 1;
   setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
   std::vector<char> payload, out;
   std::string key;
+  // An allocation that fails inside a request (a huge but admissible size on a small machine) ends THIS
+  // connection; an exception leaving a connection thread would abort the whole task.
+  try {
   for (;;) {
     ReqHeader h;
     if (!read_full(fd, &h, sizeof(h))) break;
-    if (h.magic != kMagic || h.key_len > (1u << 16) || h.payload_len > (1ull << 33)) break;
+    // Sizes come from the peer: bound them per operation BEFORE anything is allocated.  Tensor payloads (writes,
+    // axpy, accumulator pushes) may be as large as the largest buffer, control blobs (keys, queue items) 64 MiB.
+    const bool tensor_op = h.op == DTF_OP_BUF_WRITE || h.op == DTF_OP_BUF_AXPY || h.op == DTF_OP_ACC_APPLY;
+    if (h.magic != kMagic || h.key_len > (1u << 16) ||
+        h.payload_len > (tensor_op ? kMaxBufFloats * sizeof(float) : kMaxBlobBytes))
+      break;
     key.resize(h.key_len);
     if (h.key_len && !read_full(fd, &key[0], h.key_len)) break;
     payload.resize(h.payload_len);
@@ -313,9 +326,15 @@ void serve_connection(Server* s, Server::Conn* self) {
       case DTF_OP_BUF_CREATE: {
         auto e = s->get(key, true);
         std::lock_guard<std::mutex> g(e->mu);
-        if (e->buf.empty()) {
-          e->buf.assign(static_cast<size_t>(h.a0), 0.0f);
-          r.value = 1;
+        if (h.a0 <= 0 || static_cast<uint64_t>(h.a0) > kMaxBufFloats) {
+          r.status = DTF_RT_BAD_REQUEST;     // (a negative or absurd size would throw in a connection thread)
+        } else if (e->buf.empty()) {
+          try {
+            e->buf.assign(static_cast<size_t>(h.a0), 0.0f);
+            r.value = 1;
+          } catch (const std::bad_alloc&) {
+            r.status = DTF_RT_BAD_REQUEST;
+          }
         } else if (static_cast<int64_t>(e->buf.size()) != h.a0) {
           r.status = DTF_RT_BAD_REQUEST;
         }
@@ -455,6 +474,8 @@ void serve_connection(Server* s, Server::Conn* self) {
     r.payload_len = out.size();
     if (!write_parts(fd, &r, sizeof(r), out.data(), out.size(), nullptr, 0)) break;
     s->bytes_out += sizeof(r) + out.size();
+  }
+  } catch (const std::exception&) {
   }
   {
     // forget the descriptor before closing it so that stop() never touches a recycled number

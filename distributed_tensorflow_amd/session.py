@@ -153,6 +153,11 @@ class Session:
         # host mirror of global_step for a local session (None: unknown, re-read from the device): saves one
         # blocking device-to-host copy per sess.run that fetches it next to a train op
         self._gs_mirror: Optional[int] = None
+        # One thread at a time inside the session: a Supervisor's checkpoint thread pulls into the same slab and
+        # staging buffers a training step is using (re-entrant: run() -> _pull(), Saver -> var_tensor()).
+        import threading
+
+        self.run_lock = threading.RLock()
         if self.config.log_device_placement:
             self._log_placement()
 
@@ -223,7 +228,7 @@ class Session:
         return self.layout.view(self.theta, v.op_name)
 
     def _pull(self):
-        with span("pull"):
+        with self.run_lock, span("pull"):
             self.store.pull(self.theta)
 
     def _run_init(self, variables: Sequence[G.Variable]):
@@ -240,9 +245,10 @@ class Session:
         if options is not None and getattr(options, "wants_trace", False):
             col = run_metadata.step_stats.collector if run_metadata is not None else Collector()
             col.sync = bool(options.wants_device_time)
-            with col, span("session.run"):
+            with self.run_lock, col, span("session.run"):
                 return self._run(fetches, feed_dict)
-        return self._run(fetches, feed_dict)
+        with self.run_lock:
+            return self._run(fetches, feed_dict)
 
     def _run(self, fetches, feed_dict):
         if self._closed:

@@ -124,6 +124,11 @@ def update_checkpoint_state(save_dir: str, model_checkpoint_path: str, all_paths
     os.replace(tmp, os.path.join(save_dir, latest_filename))
 
 
+import contextlib
+
+_NO_LOCK = contextlib.nullcontext()
+
+
 class Saver:
     def __init__(self, var_list=None, max_to_keep: int = 5, name: str = "save"):
         self.var_list = var_list
@@ -135,7 +140,8 @@ class Saver:
 
     def save(self, sess, save_path: str, global_step=None, latest_filename: str = CHECKPOINT_STATE,
              write_meta_graph: bool = True) -> str:
-        with span("checkpoint_save"):
+        # (the session's lock: a save from the Supervisor's checkpoint thread must not interleave with a step)
+        with getattr(sess, "run_lock", _NO_LOCK), span("checkpoint_save"):
             return self._save(sess, save_path, global_step, latest_filename, write_meta_graph)
 
     def _save(self, sess, save_path, global_step, latest_filename, write_meta_graph) -> str:
@@ -182,6 +188,10 @@ class Saver:
         os.replace(prefix + ".meta.tmp", prefix + ".meta")
 
     def restore(self, sess, save_path: str):
+        with getattr(sess, "run_lock", _NO_LOCK):
+            self._restore(sess, save_path)
+
+    def _restore(self, sess, save_path: str):
         mark("checkpoint_restore", path=save_path)
         values = read_bundle(save_path)
         for v in self._variables(sess):
