@@ -113,6 +113,14 @@ class QueueRunner:
                         break
                     required = max(1, min(opt.replicas_to_aggregate, live))
                 try:
+                    if hasattr(store, "take_apply_release"):
+                        # take_grad of every accumulator, the apply, the step bump and the token deal: one request
+                        # to the shard that keeps global_step (tfdist_between_sync.py:65-68, 86-89)
+                        with span("aggregate_apply_release", required=required):
+                            store.take_apply_release(clients, required, opt.lr_value(), opt.tokens_per_step, timeout=0.5)
+                        self.rounds += 1
+                        idle_since = None
+                        continue
                     with span("aggregate_apply", required=required):
                         step = store.take_apply_all(clients, required, opt.lr_value(), timeout=0.5)
                 except TimeoutError:

@@ -13,17 +13,24 @@ from then on move **no tensor bytes through any server**:
                ``use_locking=False`` in the reference (tfdist_between.py:65);
                ``use_locking=True`` brackets the launch with a mutex kept by the
                ps task's native server;
-* sync push    the worker copies its gradient into ITS mailbox row next to the
-               shard (no atomics, no write conflicts), synchronises its stream
-               and queues an arrival record (worker index, ``local_step``) on
-               the ps control plane; the chief aggregator pops arrivals until
-               it holds the required number of fresh ones (records older than
-               the accumulator step are dropped as stale), applies
-               ``p -= lr/n * sum(their mailboxes)`` with n SGD launches on its
-               own stream, bumps ``global_step`` and deals one token to every
-               worker.  A mailbox is rewritten only after its owner received
-               the token of the round that consumed it, which is why this
-               transport insists on ``replicas_to_aggregate == total_num_replicas``.
+* sync push    the worker copies its gradient into one of ITS two mailbox rows
+               next to the shard (no atomics, no write conflicts; the rows
+               alternate with the worker's pushes), synchronises its stream,
+               and with ONE request to the ps control plane queues an arrival
+               record (worker index, ``local_step``, mailbox row) and blocks for
+               its token; the chief aggregator takes the arrivals of a round
+               with one request, keeps the required number of fresh ones
+               (records older than the accumulator step are dropped as stale),
+               applies ``p -= lr/n * sum(their mailboxes)`` with ONE launch per
+               shard on its own stream, bumps ``global_step`` and deals one
+               token to every worker.  With ``replicas_to_aggregate ==
+               total_num_replicas`` a mailbox row is rewritten only after its
+               owner received the token of the round that consumed it.  With
+               backup workers (``replicas_to_aggregate < total_num_replicas``) a
+               replica can hold spare tokens and run ahead of the aggregator;
+               the two rows per worker keep a gradient that is being summed
+               apart from the one being written, as long as the aggregator is
+               less than two of that worker's steps behind.
 
 This is the path for tasks that share a GPU — RCCL refuses two ranks on one
 device — e.g. "1 PS + 1 worker on one MI355X" and the reference's scenario of a
@@ -145,7 +152,8 @@ class IpcVariableStore:
         self._gs_off = o - layout.shard_range[self._gs_shard][0]
         self._lr_t = torch.zeros(1, dtype=torch.float32, device=device)
         self._lr_val = None
-        self._arrived: List[int] = []     # aggregator: workers whose mailbox is part of the open round
+        self._arrived: List[tuple] = []   # aggregator: (worker, mailbox row) of the gradients of the open round
+        self._pushes = 0                   # this worker's pushes so far (its two mailbox rows alternate)
         self._acc_step = 0                 # aggregator: rounds applied so far (the accumulator step)
 
     def _c(self, k: int):
@@ -170,8 +178,8 @@ class IpcVariableStore:
     def _params(self, k: int) -> torch.Tensor:
         return self._map(k)[0, :self.layout.shard_numel(k)] if self.layout.shard_numel(k) else self._map(k)[0, :0]
 
-    def _mailbox(self, k: int, worker: int) -> torch.Tensor:
-        return self._map(k)[1 + worker, :self.layout.shard_numel(k)]
+    def _mailbox(self, k: int, worker: int, slot: int = 0) -> torch.Tensor:
+        return self._map(k)[1 + 2 * worker + (slot & 1), :self.layout.shard_numel(k)]
 
     # -- lifecycle ---------------------------------------------------------------------
     def initialized(self) -> bool:
@@ -190,7 +198,7 @@ class IpcVariableStore:
 
     def _request_allocation(self):
         for k in range(self.n):
-            self._c(k).set(ALLOC_KEY, struct.pack("<qq", self.layout.shard_numel(k), 1 + self.n_workers))
+            self._c(k).set(ALLOC_KEY, struct.pack("<qq", self.layout.shard_numel(k), 1 + 2 * self.n_workers))
         for k in range(self.n):
             self._map(k)
 
@@ -287,22 +295,40 @@ class IpcVariableStore:
         return d
 
     # -- SyncReplicas protocol ------------------------------------------------------------------
-    def push_accumulate(self, grads: torch.Tensor) -> bool:
+    def _deposit(self, grads: torch.Tensor) -> bytes:
+        slot = self._pushes & 1
+        self._pushes += 1
         for k in range(self.n):
             a, b = self.layout.shard_range[k]
             if b > a:
-                self._mailbox(k, self.widx).copy_(grads[a:b], non_blocking=True)
+                self._mailbox(k, self.widx, slot).copy_(grads[a:b], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is queued
-        self._c(self._gs_shard).qpush(ARRIVAL_Q, struct.pack("<qq", self.widx, self.local_step))
+        return struct.pack("<qqq", self.widx, self.local_step, slot)
+
+    def push_accumulate(self, grads: torch.Tensor) -> bool:
+        self._c(self._gs_shard).qpush(ARRIVAL_Q, self._deposit(grads))
         return True
+
+    def _no_token(self):
+        return TimeoutError(
+            f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
+            f"is gone (replicas_to_aggregate == total_num_replicas leaves no spare)")
 
     def dequeue_token(self) -> int:
         try:
             tok = self._c(self._gs_shard).qpop(token_key(self.widx), timeout=self.timeout)
         except TimeoutError:
-            raise TimeoutError(
-                f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
-                f"is gone (replicas_to_aggregate == total_num_replicas leaves no spare)") from None
+            raise self._no_token() from None
+        self.local_step = struct.unpack("<q", tok)[0]
+        return self.local_step
+
+    def push_accumulate_and_wait(self, grads: torch.Tensor) -> int:
+        """``push_accumulate`` + ``dequeue_token`` as ONE request to the control plane."""
+        rec = self._deposit(grads)
+        try:
+            tok = self._c(self._gs_shard).qpush_pop(ARRIVAL_Q, rec, token_key(self.widx), timeout=self.timeout)
+        except TimeoutError:
+            raise self._no_token() from None
         self.local_step = struct.unpack("<q", tok)[0]
         return self.local_step
 
@@ -328,32 +354,51 @@ class IpcVariableStore:
         ctl = clients[self._gs_shard]
         deadline = time.time() + timeout
         while len(self._arrived) < num_required:
-            rec = ctl.qpop(ARRIVAL_Q, timeout=max(0.0, deadline - time.time()))   # raises TimeoutError
-            w, step = struct.unpack("<qq", rec)
-            if step < self._acc_step:
-                self.dropped += 1                  # stale: its round was applied without it
-            elif w not in self._arrived:
-                self._arrived.append(int(w))
+            # the arrivals still missing, in one request (TimeoutError when none came)
+            got, recs = ctl.qpop_n(ARRIVAL_Q, num_required - len(self._arrived),
+                                   timeout=max(0.0, deadline - time.time()))
+            for i in range(got):
+                w, step, slot = struct.unpack_from("<qqq", recs, 24 * i)
+                if step < self._acc_step:
+                    self.dropped += 1              # stale: its round was applied without it
+                elif all(w != a for a, _ in self._arrived):
+                    self._arrived.append((int(w), int(slot)))
+            if len(self._arrived) < num_required and time.time() >= deadline:
+                raise TimeoutError("sync aggregation: not enough fresh gradients yet")
         stream = getattr(self, "_agg_stream", None)
         if stream is None:
             stream = self._agg_stream = torch.cuda.Stream(device=self.device)
             self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._agg_lr_val = None
         n = len(self._arrived)
         with torch.cuda.stream(stream):
-            self._agg_lr.fill_(float(lr))
+            if self._agg_lr_val != lr:
+                self._agg_lr.fill_(float(lr))
+                self._agg_lr_val = lr
             for k in range(self.n):
                 if not self.layout.shard_numel(k):
                     continue
                 p = self._params(k)
-                for i, w in enumerate(self._arrived):
-                    gs = p[self._gs_off:self._gs_off + 1] if (i == n - 1 and k == self._gs_shard) else None
-                    hb.sgd_apply_(p, self._mailbox(k, w), self._agg_lr, 1.0 / n, False, gs)
-        stream.synchronize()
+                gs = p[self._gs_off:self._gs_off + 1] if k == self._gs_shard else None
+                boxes = [self._mailbox(k, w, slot) for w, slot in self._arrived]
+                if n <= 16:         # take_grad of every accumulator + the apply + the step bump: one launch
+                    hb.sum_apply_(p, boxes, self._agg_lr, 1.0 / n, gs)
+                else:
+                    for i, box in enumerate(boxes):
+                        hb.sgd_apply_(p, box, self._agg_lr, 1.0 / n, False, gs if i == n - 1 else None)
+        stream.synchronize()                      # the tokens must not overtake the update
         self._arrived = []
         self._acc_step += 1
         # == global_step: read from the shard when the aggregation began, bumped once per round by the last apply
         # above (no device-to-host copy on the path every replica is waiting on)
         return self._acc_step
+
+    def take_apply_release(self, clients, num_required: int, lr: float, tokens: int, timeout: float) -> int:
+        """Chief aggregator, a whole round: arrivals (one request), the update (one launch per shard), tokens (one
+        request).  A TimeoutError leaves the round open."""
+        step = self.take_apply_all(clients, num_required, lr, timeout)
+        self.enqueue_tokens(clients, step, tokens)
+        return step
 
     def enqueue_tokens(self, clients, step: int, n: int):
         tok = struct.pack("<q", int(step))

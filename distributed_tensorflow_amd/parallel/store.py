@@ -213,6 +213,31 @@ class RemoteVariableStore:
             self.dropped += 1
         return accepted
 
+    def push_accumulate_and_wait(self, grads: torch.Tensor) -> int:
+        """``push_accumulate`` + ``dequeue_token`` with one request fewer: the push to the shard that keeps
+        ``global_step`` (sent last) also blocks for this worker's token."""
+        self._stage_grads(grads)
+        accepted = True
+        order = [k for k in range(self.n) if k != self._gs_shard] + [self._gs_shard]
+        tok = None
+        for k in order:
+            a, b = self.layout.shard_range[k]
+            if k == self._gs_shard:
+                try:
+                    ok, tok = self._c(k).acc_apply_then_pop(SHARD_ACC, self._ghost[a:b], self.local_step,
+                                                            token_key(self.widx), timeout=self.timeout)
+                except TimeoutError:
+                    raise TimeoutError(
+                        f"sync barrier: no token within {self.timeout:.0f}s — a replica or the chief aggregator "
+                        f"is gone (replicas_to_aggregate == total_num_replicas leaves no spare)") from None
+                accepted &= ok
+            elif b > a:
+                accepted &= self._c(k).acc_apply(SHARD_ACC, self._ghost[a:b], self.local_step)
+        if not accepted:
+            self.dropped += 1
+        self.local_step = struct.unpack("<q", tok)[0]
+        return self.local_step
+
     def dequeue_token(self) -> int:
         """Worker: block until the chief released this worker's token; it carries the new global step.
 
@@ -274,6 +299,24 @@ class RemoteVariableStore:
             self._agg_pos += 1
         self._agg_pos = 0
         return clients[self._gs_shard].buf_add_scalar(SHARD_BUF, self._gs_off_in_shard, 1.0)
+
+    def take_apply_release(self, clients, num_required: int, lr: float, tokens: int, timeout: float) -> int:
+        """Chief aggregator, a whole round: every shard takes and applies its mean gradient; the request to the
+        shard that keeps ``global_step`` (sent last) also bumps the step and deals the tokens, server-side."""
+        per_worker = spread_tokens(tokens, self.n_workers)
+        if not (per_worker[0] > 0 and len(set(per_worker)) == 1):
+            step = self.take_apply_all(clients, num_required, lr, timeout)      # uneven deal: separate requests
+            self.enqueue_tokens(clients, step, tokens)
+            return step
+        order = [k for k in range(self.n) if k != self._gs_shard and self.layout.shard_numel(k)]
+        while self._agg_pos < len(order):
+            clients[order[self._agg_pos]].acc_take_apply(SHARD_ACC, SHARD_BUF, num_required, lr, timeout=timeout)
+            self._agg_pos += 1
+        step = clients[self._gs_shard].acc_take_apply_release(
+            SHARD_ACC, SHARD_BUF, num_required, lr, self._gs_off_in_shard, TOKEN_Q, self.n_workers,
+            copies=per_worker[0], timeout=timeout)
+        self._agg_pos = 0
+        return step
 
     def aggregator_clients(self):
         return [self.server.new_client("ps", k) for k in range(self.n)]

@@ -16,6 +16,8 @@ extern "C" {
 
 // request flags
 #define DTF_FLAG_LOCK 1
+#define DTF_FLAG_RELEASE 4  /* ACC_TAKE_APPLY: also bump the step counter and deal the round's tokens */
+#define DTF_FLAG_THEN_POP 8 /* ACC_APPLY: key = accumulator \x01 queue; then block for an item of that queue */
 #define DTF_FLAG_FANOUT 2   /* QPUSH: key is a prefix, the payload goes to the queues key/0 .. key/(a1-1) */
 
 // operations
@@ -38,6 +40,12 @@ extern "C" {
 #define DTF_OP_ACC_SET_STEP 16
 #define DTF_OP_BUF_ADD_SCALAR 17
 #define DTF_OP_ACC_INFO 18
+// One round trip instead of two: push the payload's item onto queue `key`, then block (a0 ms) for an item of a
+// SECOND queue.  Payload = u16 length of the second queue's name, that name, the item to push.
+#define DTF_OP_QPUSH_POP 19
+// Pop a0 items at once: blocks (a1 ms) until a0 are queued; on expiry returns the ones that are (status TIMEOUT
+// if none).  Reply payload = the items back to back (callers use fixed-size items); value = items returned.
+#define DTF_OP_QPOP_N 20
 
 void* dtf_server_start(const char* host, int port, int* out_port);
 int dtf_server_port(void* server);

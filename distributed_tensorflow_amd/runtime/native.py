@@ -22,9 +22,11 @@ _lib = None
 OK, TIMEOUT, BAD_REQUEST, IO_ERROR, TOO_SMALL = 0, 1, 2, 3, 4
 FLAG_LOCK = 1
 FLAG_FANOUT = 2
+FLAG_RELEASE = 4
+FLAG_THEN_POP = 8
 (OP_PING, OP_SET, OP_GET, OP_ADD, OP_WAIT_GE, OP_QPUSH, OP_QPOP, OP_DEL, OP_SHUTDOWN, OP_QLEN,
  OP_BUF_CREATE, OP_BUF_WRITE, OP_BUF_READ, OP_BUF_AXPY, OP_ACC_APPLY, OP_ACC_TAKE_APPLY, OP_ACC_SET_STEP,
- OP_BUF_ADD_SCALAR, OP_ACC_INFO) = range(19)
+ OP_BUF_ADD_SCALAR, OP_ACC_INFO, OP_QPUSH_POP, OP_QPOP_N) = range(21)
 
 
 class RuntimeError_(RuntimeError):
@@ -213,6 +215,21 @@ class StoreClient:
         self._ok(st, f"qpop {key}")
         return data
 
+    def qpush_pop(self, push_key: str, value: bytes, pop_key: str, timeout: float = 60.0) -> bytes:
+        """Push ``value`` onto ``push_key`` and block for an item of ``pop_key``: ONE round trip."""
+        name = pop_key.encode()
+        st, _, data = self._call(OP_QPUSH_POP, push_key, a0=int(timeout * 1000),
+                                 payload=len(name).to_bytes(2, "little") + name + bytes(value))
+        self._ok(st, f"qpush_pop {push_key} -> {pop_key}")
+        return data
+
+    def qpop_n(self, key: str, count: int, timeout: float = 60.0) -> Tuple[int, bytes]:
+        """Up to ``count`` items in one request: waits until ``count`` are queued, returns those present when the
+        time is up (TimeoutError if none).  -> (items returned, their bytes back to back)."""
+        st, v, data = self._call(OP_QPOP_N, key, a0=int(count), a1=int(timeout * 1000))
+        self._ok(st, f"qpop_n {key}")
+        return v, data
+
     def qlen(self, key: str) -> int:
         st, v, _ = self._call(OP_QLEN, key)
         self._ok(st, f"qlen {key}")
@@ -262,11 +279,32 @@ class StoreClient:
         self._ok(st, f"acc_apply {key}")
         return bool(v)
 
+    def acc_apply_then_pop(self, key: str, g: np.ndarray, local_step: int, pop_key: str,
+                           timeout: float = 60.0) -> Tuple[bool, bytes]:
+        """``acc_apply`` and then a blocking ``qpop(pop_key)`` in ONE round trip -> (accepted, popped item)."""
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        st, v, data = self._call(OP_ACC_APPLY, key + "\x01" + pop_key, flags=FLAG_THEN_POP, a0=local_step,
+                                 a1=int(timeout * 1000), payload=g)
+        self._ok(st, f"acc_apply_then_pop {key} -> {pop_key}")
+        return bool(v & 1), data
+
     def acc_take_apply(self, key: str, var_key: str, num_required: int, lr: float, timeout: float = 60.0) -> int:
         """Wait for num_required gradients, apply their mean to var_key with rate lr; returns the count taken."""
         st, v, _ = self._call(OP_ACC_TAKE_APPLY, key, a0=num_required, a1=int(timeout * 1000), f0=lr,
                               payload=var_key.encode())
         self._ok(st, f"acc_take_apply {key} (have {v} of {num_required})")
+        return v
+
+    def acc_take_apply_release(self, key: str, var_key: str, num_required: int, lr: float, step_offset: int,
+                               token_prefix: str, fanout: int, copies: int = 1, timeout: float = 60.0) -> int:
+        """The chief's whole round in ONE request: wait for num_required gradients, apply their mean to var_key,
+        bump the step counter var_key[step_offset] and deal ``copies`` tokens carrying the new step into the queues
+        ``token_prefix/0 .. token_prefix/(fanout-1)``.  Returns the new step."""
+        payload = (var_key.encode() + b"\0" + token_prefix.encode() + b"\0"
+                   + struct.pack("<qqq", int(step_offset), int(fanout), int(copies)))
+        st, v, _ = self._call(OP_ACC_TAKE_APPLY, key, flags=FLAG_RELEASE, a0=num_required, a1=int(timeout * 1000),
+                              f0=lr, payload=payload)
+        self._ok(st, f"acc_take_apply_release {key}")
         return v
 
     def acc_set_step(self, key: str, step: int):

@@ -317,6 +317,55 @@ void serve_connection(Server* s, Server::Conn* self) {
         }
         break;
       }
+      case DTF_OP_QPUSH_POP: {
+        // deposit + wait in one request (a synchronous replica's "here is my gradient, wake me with my token")
+        if (payload.size() < 2) {
+          r.status = DTF_RT_BAD_REQUEST;
+          break;
+        }
+        uint16_t klen = 0;
+        std::memcpy(&klen, payload.data(), 2);
+        if (payload.size() < 2u + klen) {
+          r.status = DTF_RT_BAD_REQUEST;
+          break;
+        }
+        const std::string pop_key(payload.data() + 2, klen);
+        {
+          auto e = s->get(key, true);
+          std::lock_guard<std::mutex> g(e->mu);
+          e->queue.emplace_back(payload.begin() + 2 + klen, payload.end());
+          e->cv.notify_all();
+        }
+        auto e2 = s->get(pop_key, true);
+        std::unique_lock<std::mutex> lk(e2->mu);
+        if (wait_until(s, *e2, lk, h.a0, [&] { return !e2->queue.empty(); })) {
+          out = std::move(e2->queue.front());
+          e2->queue.pop_front();
+          r.value = static_cast<int64_t>(e2->queue.size());
+        } else {
+          r.status = DTF_RT_TIMEOUT;
+        }
+        break;
+      }
+      case DTF_OP_QPOP_N: {
+        if (h.a0 < 1 || h.a0 > 65536) {
+          r.status = DTF_RT_BAD_REQUEST;
+          break;
+        }
+        auto e = s->get(key, true);
+        std::unique_lock<std::mutex> lk(e->mu);
+        const size_t want = static_cast<size_t>(h.a0);
+        (void)wait_until(s, *e, lk, h.a1, [&] { return e->queue.size() >= want; });
+        size_t n = 0;
+        while (n < want && !e->queue.empty()) {
+          out.insert(out.end(), e->queue.front().begin(), e->queue.front().end());
+          e->queue.pop_front();
+          ++n;
+        }
+        r.value = static_cast<int64_t>(n);
+        if (n == 0) r.status = DTF_RT_TIMEOUT;
+        break;
+      }
       case DTF_OP_QLEN: {
         auto e = s->get(key, true);
         std::lock_guard<std::mutex> g(e->mu);
@@ -400,53 +449,124 @@ void serve_connection(Server* s, Server::Conn* self) {
       }
       case DTF_OP_ACC_APPLY: {
         // a0 = local_step of the pushing worker; stale gradients are dropped.
-        auto e = s->get(key, true);
-        const size_t n = payload.size() / sizeof(float);
-        std::lock_guard<std::mutex> g(e->mu);
-        if (e->acc.empty()) e->acc.assign(n, 0.0f);
-        if (e->acc.size() != n) {
-          r.status = DTF_RT_BAD_REQUEST;
-          break;
+        // With DTF_FLAG_THEN_POP the key is  accumulator \x01 queue  and the request then blocks (a1 ms) for an
+        // item of that queue, which is the reply payload: a synchronous replica's push and its wait for the
+        // token in one round trip.  (value: bit 0 = gradient accepted.)
+        std::string acc_key = key, pop_key;
+        const bool then_pop = (h.flags & DTF_FLAG_THEN_POP) != 0;
+        if (then_pop) {
+          const size_t cut = key.find('\x01');
+          if (cut == std::string::npos) {
+            r.status = DTF_RT_BAD_REQUEST;
+            break;
+          }
+          acc_key = key.substr(0, cut);
+          pop_key = key.substr(cut + 1);
         }
-        if (h.a0 < e->acc_step) {
-          e->acc_dropped++;
-          r.value = 0;
-        } else {
-          const float* gsrc = reinterpret_cast<const float*>(payload.data());
-          for (size_t i = 0; i < n; ++i) e->acc[i] += gsrc[i];
-          e->acc_count++;
-          r.value = 1;
-          e->cv.notify_all();
+        auto e = s->get(acc_key, true);
+        const size_t n = payload.size() / sizeof(float);
+        {
+          std::lock_guard<std::mutex> g(e->mu);
+          if (e->acc.empty()) e->acc.assign(n, 0.0f);
+          if (e->acc.size() != n) {
+            r.status = DTF_RT_BAD_REQUEST;
+            break;
+          }
+          if (h.a0 < e->acc_step) {
+            e->acc_dropped++;
+            r.value = 0;
+          } else {
+            const float* gsrc = reinterpret_cast<const float*>(payload.data());
+            for (size_t i = 0; i < n; ++i) e->acc[i] += gsrc[i];
+            e->acc_count++;
+            r.value = 1;
+            e->cv.notify_all();
+          }
+        }
+        if (then_pop) {
+          auto q = s->get(pop_key, true);
+          std::unique_lock<std::mutex> lk(q->mu);
+          if (wait_until(s, *q, lk, h.a1, [&] { return !q->queue.empty(); })) {
+            out = std::move(q->queue.front());
+            q->queue.pop_front();
+          } else {
+            r.status = DTF_RT_TIMEOUT;
+          }
         }
         break;
       }
       case DTF_OP_ACC_TAKE_APPLY: {
         // key = accumulator; payload = name of the variable buffer; a0 = required
-        // gradients; a1 = timeout ms; f0 = learning rate; flags bit1 = only take (no apply).
+        // gradients; a1 = timeout ms; f0 = learning rate.
         // On success: var[off..] -= lr * mean(acc); accumulator reset; its step += 1.
+        // With DTF_FLAG_RELEASE the payload is  var name \0 token prefix \0 {int64 step offset, fanout, copies}
+        // and the same request also bumps the step counter var[step offset] and deals `copies` tokens carrying
+        // the new step into prefix/0 .. prefix/(fanout-1): the chief's whole round (take_grad, apply, step,
+        // enqueue_many of SyncReplicasOptimizer) in one request.
         auto acc = s->get(key, true);
-        const std::string var_key(payload.begin(), payload.end());
+        std::string var_key(payload.begin(), payload.end());
+        std::string token_prefix;
+        int64_t rel[3] = {0, 0, 0};
+        const bool release = (h.flags & DTF_FLAG_RELEASE) != 0;
+        if (release) {
+          const char* p0 = payload.data();
+          const char* pe = p0 + payload.size();
+          const char* z1 = static_cast<const char*>(std::memchr(p0, 0, payload.size()));
+          const char* z2 = z1 ? static_cast<const char*>(std::memchr(z1 + 1, 0, static_cast<size_t>(pe - z1 - 1))) : nullptr;
+          if (!z1 || !z2 || pe - (z2 + 1) != static_cast<long>(sizeof(rel))) {
+            r.status = DTF_RT_BAD_REQUEST;
+            break;
+          }
+          var_key.assign(p0, z1);
+          token_prefix.assign(z1 + 1, z2);
+          std::memcpy(rel, z2 + 1, sizeof(rel));
+          if (rel[0] < 0 || rel[1] < 0 || rel[1] > 65536 || rel[2] < 1 || rel[2] > 65536) {
+            r.status = DTF_RT_BAD_REQUEST;
+            break;
+          }
+        }
         auto var = s->get(var_key, false);
         if (!var) {
           r.status = DTF_RT_BAD_REQUEST;
           break;
         }
-        std::unique_lock<std::mutex> lk(acc->mu);
-        if (!wait_until(s, *acc, lk, h.a1, [&] { return acc->acc_count >= h.a0 && h.a0 > 0; })) {
-          r.status = DTF_RT_TIMEOUT;
-          r.value = acc->acc_count;
-          break;
-        }
-        const float scale = -static_cast<float>(h.f0) / static_cast<float>(acc->acc_count);
+        int64_t new_step = 0;
         {
-          std::lock_guard<std::mutex> vg(var->mu);
-          const size_t n = acc->acc.size() < var->buf.size() ? acc->acc.size() : var->buf.size();
-          for (size_t i = 0; i < n; ++i) var->buf[i] += scale * acc->acc[i];
+          std::unique_lock<std::mutex> lk(acc->mu);
+          if (!wait_until(s, *acc, lk, h.a1, [&] { return acc->acc_count >= h.a0 && h.a0 > 0; })) {
+            r.status = DTF_RT_TIMEOUT;
+            r.value = acc->acc_count;
+            break;
+          }
+          const float scale = -static_cast<float>(h.f0) / static_cast<float>(acc->acc_count);
+          {
+            std::lock_guard<std::mutex> vg(var->mu);
+            if (release && static_cast<size_t>(rel[0]) >= var->buf.size()) {
+              r.status = DTF_RT_BAD_REQUEST;
+              break;
+            }
+            const size_t n = acc->acc.size() < var->buf.size() ? acc->acc.size() : var->buf.size();
+            for (size_t i = 0; i < n; ++i) var->buf[i] += scale * acc->acc[i];
+            if (release) {
+              var->buf[rel[0]] += 1.0f;
+              new_step = static_cast<int64_t>(var->buf[rel[0]] + 0.5f);
+            }
+          }
+          r.value = release ? new_step : acc->acc_count;
+          std::fill(acc->acc.begin(), acc->acc.end(), 0.0f);
+          acc->acc_count = 0;
+          acc->acc_step += 1;
         }
-        r.value = acc->acc_count;
-        std::fill(acc->acc.begin(), acc->acc.end(), 0.0f);
-        acc->acc_count = 0;
-        acc->acc_step += 1;
+        if (release) {
+          std::vector<char> tok(sizeof(int64_t));
+          std::memcpy(tok.data(), &new_step, sizeof(int64_t));
+          for (int64_t w = 0; w < rel[1]; ++w) {
+            auto q = s->get(token_prefix + "/" + std::to_string(w), true);
+            std::lock_guard<std::mutex> g(q->mu);
+            for (int64_t i = 0; i < rel[2]; ++i) q->queue.push_back(tok);
+            q->cv.notify_all();
+          }
+        }
         break;
       }
       case DTF_OP_ACC_SET_STEP: {

@@ -565,10 +565,14 @@ class Session:
             if not self._local_step_ready:
                 self.store.sync_local_step()
                 self._local_step_ready = True
-            with span("push_accumulate"):
-                self.store.push_accumulate(self.grad)
-            with span("token_wait"):
-                self.store.dequeue_token()
+            if hasattr(self.store, "push_accumulate_and_wait"):
+                with span("push_accumulate_token_wait"):      # deposit + wait for the token: one round trip
+                    self.store.push_accumulate_and_wait(self.grad)
+            else:
+                with span("push_accumulate"):
+                    self.store.push_accumulate(self.grad)
+                with span("token_wait"):
+                    self.store.dequeue_token()
         elif isinstance(opt, SyncReplicasOptimizer):
             # one local replica: aggregate of one
             with span("push_apply"):

@@ -154,3 +154,54 @@ def test_store_group_gathers_objects_and_synchronises_tasks(server):
             assert [o["rank"] for o in got] == [0, 1, 2] and all(o["round"] == round_no for o in got)
             assert got[2]["blob"] == b"\x02" * 64
     assert [kind for kind, _ in order[:world]] == ["before"] * world      # nobody passed before the slowest arrived
+
+
+def test_push_and_wait_in_one_round_trip_and_bulk_pop(server):
+    """QPUSH_POP (a replica's "gradient is there, wake me with my token") and QPOP_N (the aggregator's arrivals)."""
+    worker, chief = _client(server), _client(server)
+    got = []
+    t = threading.Thread(target=lambda: got.append(worker.qpush_pop("arrivals", b"w0-step7", "tokens/0", timeout=5)))
+    t.start()
+    n, recs = chief.qpop_n("arrivals", 1, timeout=5)
+    assert (n, recs) == (1, b"w0-step7") and not got          # the worker is still blocked on its token
+    chief.qpush("tokens/0", struct.pack("<q", 8))
+    t.join()
+    assert struct.unpack("<q", got[0])[0] == 8
+    with pytest.raises(TimeoutError):
+        worker.qpush_pop("arrivals", b"x", "tokens/0", timeout=0.1)
+    for i in range(3):
+        chief.qpush("arrivals", bytes([i]) * 4)
+    n, recs = chief.qpop_n("arrivals", 8, timeout=0.2)        # fewer than asked for when the time is up
+    assert n == 4 and recs == b"x" + b"\x00" * 4 + b"\x01" * 4 + b"\x02" * 4
+    with pytest.raises(TimeoutError):
+        chief.qpop_n("arrivals", 1, timeout=0.05)
+
+
+def test_chief_round_in_one_request_and_push_that_waits_for_its_token(server):
+    """ACC_TAKE_APPLY with the release flag = take_grad + apply + step bump + token deal; ACC_APPLY with the
+    then-pop flag = a synchronous replica's push and token wait."""
+    chief = _client(server)
+    workers = [_client(server) for _ in range(2)]
+    chief.buf_create("var", 5)
+    chief.buf_write("var", np.array([10.0, 10.0, 10.0, 10.0, 3.0], dtype=np.float32))     # element 4: the step
+    chief.acc_set_step("acc", 3)
+    results = [None, None]
+
+    def push(i):
+        g = np.array([1.0, 2.0, 3.0, 4.0, 0.0], dtype=np.float32) * (i + 1)
+        results[i] = workers[i].acc_apply_then_pop("acc", g, 3, f"tok/{i}", timeout=5)
+
+    threads = [threading.Thread(target=push, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    step = chief.acc_take_apply_release("acc", "var", 2, 0.5, 4, "tok", 2, copies=1, timeout=5)
+    for t in threads:
+        t.join()
+    assert step == 4
+    assert all(ok and struct.unpack("<q", tok)[0] == 4 for ok, tok in results)
+    got = chief.buf_read("var", 5)
+    np.testing.assert_allclose(got, [10 - 0.5 * 1.5, 10 - 0.5 * 3.0, 10 - 0.5 * 4.5, 10 - 0.5 * 6.0, 4.0])
+    # a stale push is dropped but still waits for (and gets) a token
+    chief.qpush("tok/0", struct.pack("<q", 9))
+    ok, tok = workers[0].acc_apply_then_pop("acc", np.zeros(5, dtype=np.float32), 2, "tok/0", timeout=5)
+    assert ok is False and struct.unpack("<q", tok)[0] == 9
