@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MODES = ["single", "auto", "sync", "towers", "xgmi", "xgmi2", "xgmi2c", "async", "xgmi_async", "async_rccl",
+MODES = ["single", "auto", "sync", "towers", "xgmi", "xgmi2", "xgmi2c", "xgmi2p", "async", "xgmi_async", "async_rccl",
          "async_lockstep", "ingraph"]
 
 

@@ -34,7 +34,7 @@ BASELINE_MULTI = 3 * 55000.0 / 6.03      # samples/s: reference README.md:249-25
 BATCH = 100
 STEPS_PER_EPOCH = 550
 LR = 0.001
-PEER_MODES = ("xgmi", "xgmi2", "xgmi2c")      # synchronous exchanges over peer-mapped HBM (parallel/xgmi.py)
+PEER_MODES = ("xgmi", "xgmi2", "xgmi2c", "xgmi2p")      # synchronous exchanges over peer-mapped HBM (parallel/xgmi.py)
 SYNC_MODES = ("towers", "sync") + PEER_MODES
 ASYNC_MODES = ("xgmi_async", "async_rccl", "async_lockstep")
 
@@ -266,7 +266,7 @@ def run_benchmark(args) -> Optional[dict]:
 
     trial_ok = {}
     if trial is not None:
-        keys = ("ok", "async_ok", "ok2", "ok2c")
+        keys = ("ok", "async_ok", "ok2", "ok2c", "ok2p")
         flag = torch.tensor([1 if trial.get(k) else 0 for k in keys], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         trial_ok = dict(zip(keys, (bool(int(v)) for v in flag.tolist())))
@@ -373,12 +373,13 @@ def run_benchmark(args) -> Optional[dict]:
     if mode == "auto":
         # library collectives first: they are the safe baseline and give the run a result early
         if share_gpu:       # (the one-GPU rehearsal keeps its gloo group out of the per-step path when it can)
-            library = () if trial_ok.get("ok") or trial_ok.get("ok2") or trial_ok.get("ok2c") else ("towers",)
+            library = () if any(trial_ok.get(k) for k in ("ok", "ok2", "ok2c", "ok2p")) else ("towers",)
         else:
             library = ("towers", "sync")
         cands = list(library)
         if not use_cpu:
-            cands += [m for m, k in (("xgmi2c", "ok2c"), ("xgmi2", "ok2"), ("xgmi", "ok")) if trial_ok.get(k)]
+            cands += [m for m, k in (("xgmi2p", "ok2p"), ("xgmi2c", "ok2c"), ("xgmi2", "ok2"), ("xgmi", "ok"))
+                      if trial_ok.get(k)]
     elif ingraph_only:
         cands = []
     else:
@@ -460,7 +461,7 @@ def run_benchmark(args) -> Optional[dict]:
             result_extra["peer_exchange_trial"] = {k: trial.get(k) for k in (
                 "ok", "ms_per_step", "identical", "healthy", "uncached_grads", "async_ok", "async_fused_push",
                 "async_ms_per_step_by_push", "async_ms_per_step", "async_loss", "ok2", "ms_per_step2", "ok2c",
-                "ms_per_step2c", "error", "error2", "error2c", "trial_s", "skipped") if k in trial}
+                "ms_per_step2c", "ok2p", "ms_per_step2p", "error", "error2", "error2c", "error2p", "trial_s", "skipped") if k in trial}
         result_extra["setup_s"] = setup
         result_extra["wall_s_until_headline"] = round(time.monotonic() - t_begin, 1)
         if rank == 0:

@@ -143,8 +143,10 @@ typedef struct DtfXgDesc {
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
   int32_t rank, world, timeout_ms;
-  int32_t compact;                      // dtf_mlp_step_xg: inbox words are bare 4-byte values, unwritten ones hold
-                                        // 0xffffffff (the inbox must be filled with that pattern beforehand)
+  int32_t compact;                      // dtf_mlp_step_xg: 1 = inbox words are bare 4-byte values, unwritten ones hold
+                                        // 0xffffffff (the inbox must be filled with that pattern beforehand);
+                                        // 2 = two-phase exchange (8-byte words): partials go to the element's owner,
+                                        // which returns the new parameter value to every peer
   int64_t step_index;                   // dtf_mlp_step_async only: element that holds global_step (< 0: none)
   int64_t shard_start[DTF_XGMI_MAX_RANKS + 1];   // dtf_mlp_step_async with n == 0: slab range of every shard
 } DtfXgDesc;

@@ -568,7 +568,8 @@ struct XgParams {
   long step_index;                        // asynchronous variant only (see xa_push): element of global_step
   unsigned start[DTF_XGMI_MAX_RANKS];     // asynchronous variant only: first slab element of every shard
   int rank, world;
-  int compact;                            // 4-byte words with a "not yet written" pattern (see xg_exchange_compact)
+  int compact;                            // 1: 4-byte words with a "not yet written" pattern (xg_exchange_compact);
+                                          // 2: two-phase exchange through the element's owner (xg_exchange_two_phase)
   long long timeout_ticks;
 };
 
@@ -628,9 +629,9 @@ __device__ __forceinline__ float xg_exchange_compact(const XgParams& x, unsigned
 // Publishes `own` as element e of exchange `seq` and returns the rank-ordered sum over all replicas.
 // W: compile-time bound on the replica count (keeps the code small and every peer's load in flight at once).
 // *failed is raised (and the caller must not apply the result) when a peer's value never arrives.
-template <int W, bool COMPACT = false>
+template <int W, int COMPACT = 0>
 __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, long e, float own, int* failed) {
-  if constexpr (COMPACT) return xg_exchange_compact<W>(x, seq, e, own, failed);
+  if constexpr (COMPACT == 1) return xg_exchange_compact<W>(x, seq, e, own, failed);
   const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
   const long slot = (seq & 1u) ? x.slot_words : 0L;
 #pragma unroll
@@ -669,6 +670,80 @@ __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, lo
   return total;
 }
 
+// Two-phase (reduce-scatter-shaped) form of the same exchange, for many replicas.  Element e belongs to replica
+// owner(e) = e / chunk (the slab cut into `world` equal ranges, the parameter-server shard of that GPU).  A thread
+// that does not own its element sends its partial to the OWNER only and waits for the owner's answer; the owner's
+// thread collects the world - 1 partials, adds them in rank order to its own, applies the SGD update and sends the
+// NEW PARAMETER VALUE to every peer.  A link carries 2 / world of the slab per step instead of all of it (159 KB
+// instead of 636 KB of 8-byte words at world = 8) for one more hop of latency, and every replica stores the very
+// same bits, computed once.  Same inbox layout and slot alternation as above: row r of a replica's inbox is
+// written by replica r only -- partials for the owner, the new value for everybody else.
+template <int W>
+__device__ __forceinline__ float xg_exchange_two_phase(const XgParams& x, unsigned seq, long e, float own, float old,
+                                                       float lr, int* failed) {
+  const long slot = (seq & 1u) ? x.slot_words : 0L;
+  const long chunk = (x.n + x.world - 1) / x.world;
+  int owner = (int)(e / chunk);
+  owner = owner < x.world ? owner : x.world - 1;
+  long long t0 = 0;
+  if (owner != x.rank) {
+    const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
+    uint64_t* theirs = x.inbox[0];
+#pragma unroll
+    for (int r = 1; r < W; ++r) theirs = (owner == r) ? x.inbox[r] : theirs;
+    __hip_atomic_store(theirs + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t* mine = x.inbox[x.rank] + slot + (long)owner * x.n + e;
+#pragma unroll 1
+    for (unsigned spin = 1;; ++spin) {
+      const uint64_t v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned)(v >> 32) == seq) return __uint_as_float((unsigned)v);
+      if ((spin & 63u) == 0u) {
+        const long long now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        if (now - t0 > x.timeout_ticks) {
+          *failed = 1;
+          return old;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  const uint64_t* mine = x.inbox[x.rank] + slot + e;
+  uint64_t v[W];
+#pragma unroll 1
+  for (unsigned spin = 1;; ++spin) {
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      if (r < x.world && r != x.rank) {
+        v[r] = __hip_atomic_load(mine + (long)r * x.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = all && (unsigned)(v[r] >> 32) == seq;
+      }
+    }
+    if (all) break;
+    if ((spin & 63u) == 0u) {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > x.timeout_ticks) {
+        *failed = 1;
+        return old;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int r = 0; r < W; ++r)
+    if (r < x.world) total += (r == x.rank) ? own : __uint_as_float((unsigned)v[r]);
+  const float fresh = old - lr * total;
+  const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(fresh);
+#pragma unroll
+  for (int r = 0; r < W; ++r)
+    if (r < x.world && r != x.rank)
+      __hip_atomic_store(x.inbox[r] + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return fresh;
+}
+
 // Asynchronous variant (XW < 0): the same per-thread outputs are not swapped but PUSHED -- each gradient element is
 // applied where the variable lives, `shard_owner(e)[e] -= lr * g`, as one fire-and-forget float atomic through
 // the peer mapping.  Shard k holds the slab elements [start[k], start[k+1]) and x.inbox[k] is the address slab
@@ -685,7 +760,7 @@ __device__ __forceinline__ void xa_push(const XgParams& x, long e, float delta) 
   (void)__hip_atomic_fetch_add(reinterpret_cast<float*>(base) + e, delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int NS, int CQ, int NA, bool YV2, int XW = 0, bool XC = false>
+template <int NS, int CQ, int NA, bool YV2, int XW = 0, int XC = 0>
 __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem, int bx, int by, int lin,
                                                 const XgParams* xg = nullptr) {
   static_assert(NS >= 1 && NS <= 4 && CQ >= 1 && CQ <= 4 && NA >= 1 && NA <= 6, "operand slots");
@@ -1003,8 +1078,14 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         // (selected with constant indices: indexing the arrays with `item` would put them into scratch memory,
         // and a kernel that uses scratch at all starts ~1 us later)
         if (!(item ? xv[1] : xv[0])) continue;
-        const float total = xg_exchange<XW, XC>(x, seq, item ? xe[1] : xe[0], item ? xown[1] : xown[0], &lost);
-        if (!lost) *(item ? xdst[1] : xdst[0]) = (item ? xold[1] : xold[0]) - lr * total;
+        if constexpr (XC == 2) {      // two-phase: the owner of the element computes the new value for everybody
+          const float fresh = xg_exchange_two_phase<XW>(x, seq, item ? xe[1] : xe[0], item ? xown[1] : xown[0],
+                                                        item ? xold[1] : xold[0], lr, &lost);
+          if (!lost) *(item ? xdst[1] : xdst[0]) = fresh;
+        } else {
+          const float total = xg_exchange<XW, XC>(x, seq, item ? xe[1] : xe[0], item ? xown[1] : xown[0], &lost);
+          if (!lost) *(item ? xdst[1] : xdst[0]) = (item ? xold[1] : xold[0]) - lr * total;
+        }
       }
       if (lost) atomicExch(&x.state[2], 1u);
     }
@@ -1019,7 +1100,7 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_kernel(BwdParams p) {
   bwd_tile16_body<NS, CQ, 2, YV2>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
-template <int NS, int CQ, bool YV2, int XW, bool XC = false>
+template <int NS, int CQ, bool YV2, int XW, int XC = 0>
 __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_xg_kernel(BwdParams p, XgParams x) {
   __shared__ __attribute__((aligned(16))) float smem[bwd16_smem_floats(2)];
   bwd_tile16_body<NS, CQ, 2, YV2, XW, XC>(p, smem, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x, &x);
@@ -1392,16 +1473,21 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
     if (fast) hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 3, true, W, XC>), grid, block, 0, stream, p, *xg);  \
     else hipLaunchKernelGGL((bwd_tile16_xg_kernel<4, 4, false, W, XC>), grid, block, 0, stream, p, *xg);      \
   } while (0)
-    if (xg_async) DTF_XG_LAUNCH(-1, false);
-    else if (xg->compact) {
-      if (xg->world <= 2) DTF_XG_LAUNCH(2, true);
-      else if (xg->world <= 4) DTF_XG_LAUNCH(4, true);
-      else if (xg->world <= 8) DTF_XG_LAUNCH(8, true);
-      else DTF_XG_LAUNCH(16, true);
-    } else if (xg->world <= 2) DTF_XG_LAUNCH(2, false);
-    else if (xg->world <= 4) DTF_XG_LAUNCH(4, false);
-    else if (xg->world <= 8) DTF_XG_LAUNCH(8, false);
-    else DTF_XG_LAUNCH(16, false);
+    if (xg_async) DTF_XG_LAUNCH(-1, 0);
+    else if (xg->compact == 1) {
+      if (xg->world <= 2) DTF_XG_LAUNCH(2, 1);
+      else if (xg->world <= 4) DTF_XG_LAUNCH(4, 1);
+      else if (xg->world <= 8) DTF_XG_LAUNCH(8, 1);
+      else DTF_XG_LAUNCH(16, 1);
+    } else if (xg->compact == 2) {
+      if (xg->world <= 2) DTF_XG_LAUNCH(2, 2);
+      else if (xg->world <= 4) DTF_XG_LAUNCH(4, 2);
+      else if (xg->world <= 8) DTF_XG_LAUNCH(8, 2);
+      else DTF_XG_LAUNCH(16, 2);
+    } else if (xg->world <= 2) DTF_XG_LAUNCH(2, 0);
+    else if (xg->world <= 4) DTF_XG_LAUNCH(4, 0);
+    else if (xg->world <= 8) DTF_XG_LAUNCH(8, 0);
+    else DTF_XG_LAUNCH(16, 0);
 #undef DTF_XG_LAUNCH
   } else if (cq <= 3 && yv2) {
     hipLaunchKernelGGL((bwd_tile16_kernel<4, 3, true>), grid, block, 0, stream, p);
@@ -1497,7 +1583,8 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) a.start[r] = 0u;
   a.rank = x->rank;
   a.world = x->world;
-  a.compact = x->compact != 0;
+  if (x->compact < 0 || x->compact > 2) return DTF_ERR_SHAPE;
+  a.compact = x->compact;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock
   return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a);
 }

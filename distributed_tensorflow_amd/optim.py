@@ -85,6 +85,12 @@ class QueueRunner:
         self.drain_idle_secs = 10.0
 
     def create_threads(self, sess, coord=None, daemon: bool = True, start: bool = False):
+        # The aggregator shares this process (and its interpreter lock) with the chief's own training loop, and
+        # every replica waits on it once per step: hand the lock over quickly (default: 5 ms).
+        import sys
+
+        if sys.getswitchinterval() > 2e-4:
+            sys.setswitchinterval(2e-4)
         t = threading.Thread(target=self._run, args=(sess, coord), name=self.name, daemon=daemon)
         if start:
             t.start()

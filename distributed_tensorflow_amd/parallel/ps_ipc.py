@@ -50,6 +50,7 @@ from typing import List, Optional
 import torch
 
 from ..ops import hip_backend as hb
+from ..utils.trace import span
 from ..variables import ShardLayout
 from .store import FINISHED_KEY, INIT_KEY, TOKEN_Q, spread_tokens, token_key
 
@@ -154,6 +155,7 @@ class IpcVariableStore:
         self._lr_val = None
         self._arrived: List[tuple] = []   # aggregator: (worker, mailbox row) of the gradients of the open round
         self._pushes = 0                   # this worker's pushes so far (its two mailbox rows alternate)
+        self._agg_plans = {}               # aggregator: launch arguments per combination of mailbox rows
         self._acc_step = 0                 # aggregator: rounds applied so far (the accumulator step)
 
     def _c(self, k: int):
@@ -298,16 +300,49 @@ class IpcVariableStore:
     def _deposit(self, grads: torch.Tensor) -> bytes:
         slot = self._pushes & 1
         self._pushes += 1
-        for k in range(self.n):
-            a, b = self.layout.shard_range[k]
-            if b > a:
-                self._mailbox(k, self.widx, slot).copy_(grads[a:b], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is queued
+        with span("deposit_gradient"):
+            for k in range(self.n):
+                a, b = self.layout.shard_range[k]
+                if b > a:
+                    self._mailbox(k, self.widx, slot).copy_(grads[a:b], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()   # bytes are in HBM before the arrival is queued
         return struct.pack("<qqq", self.widx, self.local_step, slot)
 
     def push_accumulate(self, grads: torch.Tensor) -> bool:
         self._c(self._gs_shard).qpush(ARRIVAL_Q, self._deposit(grads))
         return True
+
+    # The gradient can be produced IN the mailbox: the backward kernel's output pointers are views of this worker's
+    # mailbox rows (one per variable, in the shard that owns the variable), so a synchronous push moves no bytes.
+    def mailbox_grad_slots(self, names: dict):
+        """[{role: tensor}, {role: tensor}]: views of this worker's two mailbox rows shaped like the variables
+        ``names[role]`` — gradient outputs for ``MLPEngine.bind_grad_slots``."""
+        slots = []
+        for slot in (0, 1):
+            views = {}
+            for role, name in names.items():
+                k = self.layout.owner_of(name)
+                o, n = self.layout.var_range[name]
+                a = self.layout.shard_range[k][0]
+                views[role] = self._map(k)[1 + 2 * self.widx + slot, o - a:o - a + n].view(self.layout.by_name[name].shape)
+            slots.append(views)
+        return slots
+
+    def next_mailbox_slot(self) -> int:
+        return self._pushes & 1
+
+    def push_deposited_and_wait(self) -> int:
+        """The gradient of this step already sits in mailbox row ``next_mailbox_slot()`` and the stream has been
+        synchronised since: announce it and wait for the token (one request)."""
+        slot = self._pushes & 1
+        self._pushes += 1
+        rec = struct.pack("<qqq", self.widx, self.local_step, slot)
+        try:
+            tok = self._c(self._gs_shard).qpush_pop(ARRIVAL_Q, rec, token_key(self.widx), timeout=self.timeout)
+        except TimeoutError:
+            raise self._no_token() from None
+        self.local_step = struct.unpack("<q", tok)[0]
+        return self.local_step
 
     def _no_token(self):
         return TimeoutError(
@@ -355,8 +390,9 @@ class IpcVariableStore:
         deadline = time.time() + timeout
         while len(self._arrived) < num_required:
             # the arrivals still missing, in one request (TimeoutError when none came)
-            got, recs = ctl.qpop_n(ARRIVAL_Q, num_required - len(self._arrived),
-                                   timeout=max(0.0, deadline - time.time()))
+            with span("wait_arrivals"):
+                got, recs = ctl.qpop_n(ARRIVAL_Q, num_required - len(self._arrived),
+                                       timeout=max(0.0, deadline - time.time()))
             for i in range(got):
                 w, step, slot = struct.unpack_from("<qqq", recs, 24 * i)
                 if step < self._acc_step:
@@ -371,22 +407,37 @@ class IpcVariableStore:
             self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._agg_lr_val = None
         n = len(self._arrived)
-        with torch.cuda.stream(stream):
+        with span("sum_apply"), torch.cuda.stream(stream):
             if self._agg_lr_val != lr:
                 self._agg_lr.fill_(float(lr))
                 self._agg_lr_val = lr
-            for k in range(self.n):
-                if not self.layout.shard_numel(k):
-                    continue
-                p = self._params(k)
-                gs = p[self._gs_off:self._gs_off + 1] if k == self._gs_shard else None
-                boxes = [self._mailbox(k, w, slot) for w, slot in self._arrived]
-                if n <= 16:         # take_grad of every accumulator + the apply + the step bump: one launch
-                    hb.sum_apply_(p, boxes, self._agg_lr, 1.0 / n, gs)
-                else:
-                    for i, box in enumerate(boxes):
-                        hb.sgd_apply_(p, box, self._agg_lr, 1.0 / n, False, gs if i == n - 1 else None)
-        stream.synchronize()                      # the tokens must not overtake the update
+            if n <= 16:             # take_grad of every accumulator + the apply + the step bump: one launch per shard
+                key = tuple(self._arrived)
+                plan = self._agg_plans.get(key)
+                if plan is None:    # device addresses of this combination of mailbox rows, built once
+                    plan = []
+                    for k in range(self.n):
+                        if not self.layout.shard_numel(k):
+                            continue
+                        p = self._params(k)
+                        gs = p[self._gs_off:self._gs_off + 1] if k == self._gs_shard else None
+                        tab = (C.c_uint64 * n)(*[self._mailbox(k, w, slot).data_ptr() for w, slot in self._arrived])
+                        plan.append((p.data_ptr(), tab, p.numel(), None if gs is None else gs.data_ptr()))
+                    self._agg_plans[key] = plan
+                lib, sh = hb.require(), stream.cuda_stream
+                for pp, tab, numel, gsp in plan:
+                    hb._check(lib.dtf_sum_apply(pp, tab, n, numel, self._agg_lr.data_ptr(), 1.0 / n, gsp, sh),
+                              "dtf_sum_apply")
+            else:
+                for k in range(self.n):
+                    if not self.layout.shard_numel(k):
+                        continue
+                    p = self._params(k)
+                    gs = p[self._gs_off:self._gs_off + 1] if k == self._gs_shard else None
+                    for i, (w, slot) in enumerate(self._arrived):
+                        hb.sgd_apply_(p, self._mailbox(k, w, slot), self._agg_lr, 1.0 / n, False, gs if i == n - 1 else None)
+        with span("sum_apply_sync"):
+            stream.synchronize()                  # the tokens must not overtake the update
         self._arrived = []
         self._acc_step += 1
         # == global_step: read from the shard when the aggregation began, bumped once per round by the last apply
@@ -397,7 +448,8 @@ class IpcVariableStore:
         """Chief aggregator, a whole round: arrivals (one request), the update (one launch per shard), tokens (one
         request).  A TimeoutError leaves the round open."""
         step = self.take_apply_all(clients, num_required, lr, timeout)
-        self.enqueue_tokens(clients, step, tokens)
+        with span("release_tokens"):
+            self.enqueue_tokens(clients, step, tokens)
         return step
 
     def enqueue_tokens(self, clients, step: int, n: int):

@@ -190,6 +190,20 @@ class PsResidentTrainer(_BaseTrainer):
                 f"({type(self.store).__name__}" + (", hipGraph chunks of %d)" % self.chunk if self.use_graph else ", eager)"))
 
 
+MAX_SPINNING_PER_GPU = 3      # processes whose cross-replica backward launches can be resident on one MI355X together
+
+
+def _device_identity(device: torch.device) -> str:
+    """A name that is equal exactly for processes using the same physical GPU of the same host."""
+    import socket
+
+    props = torch.cuda.get_device_properties(device)
+    tag = getattr(props, "uuid", None)
+    if tag is None:
+        tag = (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1), getattr(props, "pci_device_id", -1))
+    return f"{socket.gethostname()}/{tag}"
+
+
 class PsSyncResidentTrainer(_BaseTrainer):
     """Synchronous replicas started the reference's way, on the device-resident tier.
 
@@ -241,6 +255,29 @@ class PsSyncResidentTrainer(_BaseTrainer):
         self.steps_done = 0
         self._graphs = {}
         group = StoreGroup(sess.server.client("ps", 0), "sync-resident", self.rank, self.world)
+        # Where do the workers run?  The exchange inside the backward launch keeps 183 workgroups per worker
+        # spinning until every peer's values are in: workers that share a GPU must all be resident on it at once,
+        # which holds for at most MAX_SPINNING_PER_GPU of them (more would wait for workgroups that cannot start,
+        # until the exchange's time limit).  Such a cluster (e.g. the reference's "1 ps + N workers on gpu0",
+        # README.md:42-86, with N > 3) uses the one-kernel exchange instead: a bounded grid after the backward.
+        places = [None] * self.world
+        group.all_gather_object(places, _device_identity(self.device))
+        sharing = max(places.count(p) for p in places)
+        forced = os.environ.get("DTF_SYNC_RESIDENT_EXCHANGE", "")
+        self.exchange = forced if forced in ("inbox", "kernel") else (
+            "kernel" if sharing > MAX_SPINNING_PER_GPU else "inbox")
+        if self.exchange == "kernel":
+            from .xgmi import XgmiExchange
+
+            if self.layout.var_range["global_step"][0] >= 4:
+                raise RuntimeError("global_step must live in the first 16 bytes of the slab")
+            self.engine.global_step = None
+            self.engine._desc = None
+            self.xg = XgmiExchange(self.rank, self.world, self.params.numel(), self.device, group=group,
+                                   uncached_grads=True, timeout_ms=timeout_ms)
+            self.engine.bind_grad_slots([{r: self.layout.view(g, n) for r, n in names.items()} for g in self.xg.grads])
+            self._xg_desc = None
+            return
         # DTF_XG_COMPACT=1: bare 4-byte words (half the bytes on a link; every worker must agree, the inbox sizes
         # are compared when the handles are exchanged)
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
@@ -249,7 +286,12 @@ class PsSyncResidentTrainer(_BaseTrainer):
 
     def _one_step(self, batch_index: int):
         with span("step"):
-            self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
+            if self.exchange == "kernel":
+                slot = self.engine.parity
+                self.engine.step_grad(batch_index, scale=1.0 / self.world, slot=slot)
+                self.xg.apply(self.params, self.lr, slot, self.global_step)
+            else:
+                self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
 
     def _capture(self, pos: int, n: int, parity: int):
         # Two warm-up steps (real exchanges, performed by every worker alike) that are rolled back.
@@ -280,7 +322,10 @@ class PsSyncResidentTrainer(_BaseTrainer):
         self.xg.close()
 
     def describe(self) -> str:
+        how = ("exchange inside the backward launch over peer-mapped HBM" if self.exchange == "inbox" else
+               "exchange as one bounded kernel after the backward (more workers share a GPU than can spin on it "
+               "together) over peer-mapped HBM")
         return (f"between-graph sync worker {self.rank} of {self.world}, device-resident: replica per worker, gradient "
-                f"exchange inside the backward launch over peer-mapped HBM (mean of {self.world}, one update per "
-                f"{self.world} batches), 2 launches/step"
+                f"{how} (mean of {self.world}, one update per "
+                f"{self.world} batches), {2 if self.exchange == 'inbox' else 3} launches/step"
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))

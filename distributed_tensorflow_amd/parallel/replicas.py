@@ -590,7 +590,7 @@ class XgmiFusedTrainer(_BaseTrainer):
     name = "xgmi2"
 
     def __init__(self, *a, group=None, timeout_ms: int = 20000, compact: bool = False, local_peers: bool = False,
-                 **kw):
+                 two_phase: bool = False, **kw):
         kw["need_grads"] = False
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
@@ -600,9 +600,11 @@ class XgmiFusedTrainer(_BaseTrainer):
         self.engine.global_step = self.global_step
         self.engine._desc = None
         self.compact = bool(compact)
-        self.name = "xgmi2c" if self.compact else "xgmi2"
+        self.two_phase = bool(two_phase)
+        self.name = "xgmi2p" if self.two_phase else ("xgmi2c" if self.compact else "xgmi2")
         self.xg = PeerInbox(self.rank, self.world, self.params.numel(), self.device, group=group,
-                            timeout_ms=timeout_ms, compact=self.compact, connect=not local_peers)
+                            timeout_ms=timeout_ms, compact=self.compact, connect=not local_peers,
+                            two_phase=self.two_phase)
         self._xg_offs = {role: self.layout.var_range[name][0] for role, name in
                          (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
                           ("b2", "biases/Variable_1"))}
@@ -622,6 +624,11 @@ class XgmiFusedTrainer(_BaseTrainer):
     close = XgmiTowerTrainer.close
 
     def describe(self):
+        if self.two_phase:
+            return (f"sync towers dp{self.world}: two-phase gradient exchange inside the backward launch over "
+                    f"peer-mapped HBM (partials to the element's owner, the PS shard of that GPU, which sums in rank "
+                    f"order, applies SGD and returns the new value to every peer: 2/{self.world} of the slab per link), "
+                    f"2 launches/step" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
         words = ("bare 4-byte values, unwritten words marked by a reserved NaN pattern," if self.compact
                  else "{number, value} words")
         return (f"sync towers dp{self.world}: gradient exchange inside the backward launch ({words} "
@@ -734,6 +741,8 @@ def build_replica_trainer(mode: str, **kw):
            "xgmi_async": XgmiAsyncTrainer}[mode]
     if mode == "xgmi2c":        # the exchange inside the backward launch with 4-byte words
         kw["compact"] = True
+    if mode == "xgmi2p":        # ... through the owner of every element (reduce-scatter shaped)
+        kw["two_phase"] = True
     if mode == "single" and kw.get("world", 1) != 1:
         raise ValueError("single mode is one process")
     return cls(**kw)

@@ -436,7 +436,7 @@ class PeerInbox:
     """
 
     def __init__(self, rank: int, world: int, numel: int, device: torch.device, group=None, timeout_ms: int = 5000,
-                 compact: bool = False, connect: bool = True):
+                 compact: bool = False, connect: bool = True, two_phase: bool = False):
         lib = hb.require()
         if not 1 <= world <= lib.dtf_xgmi_max_ranks():
             raise ValueError(f"world must be 1..{lib.dtf_xgmi_max_ranks()}")
@@ -445,6 +445,11 @@ class PeerInbox:
         self.timeout_ms = int(timeout_ms)
         # compact: bare 4-byte values, a word nobody has written yet holds 0xffffffff (half the bytes on a link)
         self.compact = bool(compact)
+        # two_phase: partials travel to the OWNER of an element only (the slab cut into `world` ranges), which answers
+        # with the new parameter value: 2 / world of the slab per link and step, one more hop (8-byte words)
+        self.two_phase = bool(two_phase)
+        if self.compact and self.two_phase:
+            raise ValueError("compact words and the two-phase exchange are separate variants")
         self.slot_bytes = self.world * self.numel * (4 if self.compact else 8)
         self._closed = False
         self._mapped: List[int] = []
@@ -458,7 +463,7 @@ class PeerInbox:
                 # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and
                 # an empty inbox, all zeros, never matches), [2]: error
                 self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
-                return {"rank": self.rank, "bytes": self.slot_bytes,       # (differs if `compact` does)
+                return {"rank": self.rank, "bytes": self.slot_bytes + (1 if self.two_phase else 0),   # (variant tag)
                         "handle": _export(self._ptr) if (self.world > 1 and connect) else b""}
 
         mine = _export_all(local)
@@ -478,7 +483,7 @@ class PeerInbox:
                     for h in everyone:
                         if h["rank"] == self.rank:
                             continue
-                        if h["bytes"] != self.slot_bytes:
+                        if h["bytes"] != self.slot_bytes + (1 if self.two_phase else 0):
                             raise RuntimeError("replicas disagree on the inbox size")
                         self._ptrs[h["rank"]] = _open(h["handle"])
                         self._mapped.append(self._ptrs[h["rank"]])
@@ -505,7 +510,7 @@ class PeerInbox:
         d.n = self.numel
         d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
         d.rank, d.world, d.timeout_ms = self.rank, self.world, self.timeout_ms
-        d.compact = int(self.compact)
+        d.compact = 2 if self.two_phase else int(self.compact)
         return d
 
     def failed(self) -> bool:

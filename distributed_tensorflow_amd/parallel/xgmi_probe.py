@@ -100,7 +100,7 @@ def main(argv=None) -> int:
         t.close()
         # the exchange inside the backward launch (2 launches per step), with 8-byte {number, value} words and with
         # bare 4-byte values (half the bytes on a link), each judged by the same criteria
-        for mode2, tag in (("xgmi2", "2"), ("xgmi2c", "2c")):
+        for mode2, tag in (("xgmi2", "2"), ("xgmi2c", "2c"), ("xgmi2p", "2p")):
             if not go_on(mode2):
                 continue
             try:

@@ -24,6 +24,7 @@ reference pays too; the device-resident fast tier (``parallel.replicas``,
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -535,6 +536,10 @@ class Session:
                     self._bind_local_update(eng, train_op, lr)
                     eng.step_fused(0)
                     applied = True
+                elif sync and self._mailbox_gradients(eng, m):
+                    # the backward kernel writes this step's gradient straight into the worker's mailbox row
+                    eng.step_grad(0, 1.0, slot=self.store.next_mailbox_slot())
+                    applied = "deposited"
                 else:
                     eng.step_grad(0, 1.0)
             with span("fetch_stats"):
@@ -559,6 +564,13 @@ class Session:
                 cache[k] = val.detach() if isinstance(val, torch.Tensor) else val
             self.generic_steps += 1
         # ---- push ----
+        if applied == "deposited":      # (the statistics fetch above synchronised the stream: the bytes are in HBM)
+            if not self._local_step_ready:
+                self.store.sync_local_step()
+                self._local_step_ready = True
+            with span("push_accumulate_token_wait"):
+                self.store.push_deposited_and_wait()
+            return
         if applied:
             return
         if sync:
@@ -581,6 +593,24 @@ class Session:
             with span("push_apply"):
                 self.store.push_apply(self.grad, lr, opt.use_locking,
                                       bump_step=train_op.attrs["global_step"] is not None)
+
+    def _mailbox_gradients(self, eng: MLPEngine, m) -> bool:
+        """Synchronous replicas on a transport with GPU-resident mailboxes: let the engine write its gradients INTO
+        this worker's mailbox rows (no copy per step).  Only when the fused model covers every trainable variable."""
+        state = getattr(eng, "_mailbox_state", None)
+        if state is None:
+            state = False
+            if hasattr(self.store, "mailbox_grad_slots") and os.environ.get("DTF_MAILBOX_GRADIENTS", "1") != "0":
+                names = {r: m[r].op_name for r in ("W1", "b1", "W2", "b2")}
+                trainable = {s.name for s in self.layout.specs if s.trainable}
+                if trainable == set(names.values()):
+                    if not self._local_step_ready:       # (allocation of the shards precedes the first mapping)
+                        self.store.sync_local_step()
+                        self._local_step_ready = True
+                    eng.bind_grad_slots(self.store.mailbox_grad_slots(names))
+                    state = True
+            eng._mailbox_state = state
+        return state
 
     def _bind_local_update(self, eng: MLPEngine, train_op, lr: float):
         """Point the engine's fused step at this train op's learning rate and step counter (cached per engine)."""

@@ -56,9 +56,9 @@ def main():
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
     if mode in ("async", "async_sep"):
         return run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=mode == "async")
-    t = build_replica_trainer({"sync2": "xgmi2", "sync2c": "xgmi2c"}.get(mode, "xgmi"), device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
+    t = build_replica_trainer({"sync2": "xgmi2", "sync2c": "xgmi2c", "sync2p": "xgmi2p"}.get(mode, "xgmi"), device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
                               chunk=3, use_graph=bool(use_graph), timeout_ms=30000,
-                              **({} if mode in ("sync2", "sync2c") else {"uncached_grads": bool(uncached)}))
+                              **({} if mode in ("sync2", "sync2c", "sync2p") else {"uncached_grads": bool(uncached)}))
     p0 = t.params.clone().cpu()
     t.prepare((steps,))
     dist.barrier()

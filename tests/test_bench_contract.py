@@ -90,8 +90,9 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     doc = json.loads([line for line in p.stdout.splitlines() if line.startswith("{")][-1])
     assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 200
     assert doc["peer_exchange_trial"]["ok"] is True and doc["peer_exchange_trial"]["identical"] is True
-    assert set(doc["mode_ms_per_step"]) == {"xgmi", "xgmi2", "xgmi2c"} and doc["ranks_seen"] == 2
+    assert set(doc["mode_ms_per_step"]) == {"xgmi", "xgmi2", "xgmi2c", "xgmi2p"} and doc["ranks_seen"] == 2
     assert doc["peer_exchange_trial"]["ok2"] is True and doc["peer_exchange_trial"]["ok2c"] is True
+    assert doc["peer_exchange_trial"]["ok2p"] is True
     assert "peer-mapped" in doc["config"]["parallelism"]          # whichever of the two exchanges was faster
     assert doc["global_step"] == 700 and doc["sec_per_epoch"] > 0 and doc["multi_gpu_measured"] is False
     a = doc["async_mode"]                                   # the asynchronous workers, measured next to it

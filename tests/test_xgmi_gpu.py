@@ -106,10 +106,12 @@ def test_one_async_worker_trains_the_same_with_either_push():
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world,use_graph,mode", [(1, True, "sync2"), (2, False, "sync2"), (2, True, "sync2"),
                                                   (3, True, "sync2"), (1, True, "sync2c"), (2, False, "sync2c"),
-                                                  (2, True, "sync2c"), (3, True, "sync2c")])
+                                                  (2, True, "sync2c"), (3, True, "sync2c"), (1, True, "sync2p"),
+                                                  (2, False, "sync2p"), (2, True, "sync2p"), (3, True, "sync2p")])
 def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_graph, mode):
     """Two launches per step: every backward thread swaps its element with the same thread of the peers
-    (``sync2``: 8-byte {number, value} words; ``sync2c``: bare 4-byte values and a "not yet written" pattern).
+    (``sync2``: 8-byte {number, value} words; ``sync2c``: bare 4-byte values and a "not yet written" pattern;
+    ``sync2p``: two phases through the owner of every element, which returns the new parameter value).
     (More than three replica processes do not fit on ONE GPU together: their spinning workgroups would wait for
     workgroups of a peer that cannot become resident.  One process per GPU has no such limit.)"""
     steps = 7
@@ -120,6 +122,7 @@ def test_exchange_inside_the_backward_launch_gives_the_same_training(world, use_
         assert r["moved"] > 1e-3
         assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r
         assert "inside the backward launch" in r["describe"]
+        assert ("two-phase" in r["describe"]) == (mode == "sync2p")
 
 
 @pytest.mark.gpu
