@@ -1,5 +1,3 @@
 set -o pipefail
-mkdir -p gpurun_out/r2/tl
-rm -f gpurun_out/r2/tl/*
-DTF_TRACE=timeline DTF_TRACE_FILE=$PWD/gpurun_out/r2/tl/trace_%p.json timeout -k 10 300 python bench/run_cluster.py --script tfdist_between_sync.py --ps 1 --workers 2 --transport ipc --epochs 4
-python bench/summarize_timeline.py gpurun_out/r2/tl/trace_*.json
+mkdir -p gpurun_out/r2
+timeout -k 10 900 python -u -m pytest tests/test_xgmi_gpu.py tests/test_session_gpu.py tests/test_bench_contract.py -m gpu -x -q --timeout 400 --timeout-method thread 2>&1 | tail -25

@@ -685,42 +685,54 @@ __device__ __forceinline__ float xg_exchange_two_phase(const XgParams& x, unsign
   const long chunk = (x.n + x.world - 1) / x.world;
   int owner = (int)(e / chunk);
   owner = owner < x.world ? owner : x.world - 1;
-  long long t0 = 0;
-  if (owner != x.rank) {
+  const bool is_owner = owner == x.rank;
+  // Lanes of ONE wave can own their elements or not (a tile straddles a range boundary), and an owner lane's
+  // answer is what the same lane of the peer's wave is waiting for: no lane may wait inside a branch the other
+  // lanes have to get past first.  So: every lane sends first, then ONE loop in which every lane polls for what
+  // it still needs and an owner answers from inside the loop the moment its partials are complete.
+  if (!is_owner) {
     const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(own);
     uint64_t* theirs = x.inbox[0];
 #pragma unroll
     for (int r = 1; r < W; ++r) theirs = (owner == r) ? x.inbox[r] : theirs;
     __hip_atomic_store(theirs + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t* mine = x.inbox[x.rank] + slot + (long)owner * x.n + e;
-#pragma unroll 1
-    for (unsigned spin = 1;; ++spin) {
-      const uint64_t v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((unsigned)(v >> 32) == seq) return __uint_as_float((unsigned)v);
-      if ((spin & 63u) == 0u) {
-        const long long now = wall_clock64();
-        if (t0 == 0) t0 = now;
-        if (now - t0 > x.timeout_ticks) {
-          *failed = 1;
-          return old;
-        }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
   }
   const uint64_t* mine = x.inbox[x.rank] + slot + e;
-  uint64_t v[W];
+  float result = old;
+  long long t0 = 0;
 #pragma unroll 1
   for (unsigned spin = 1;; ++spin) {
     bool all = true;
+    uint64_t v[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) {
-      if (r < x.world && r != x.rank) {
+      // an owner needs the word of every peer; everybody else only the owner's
+      const bool need = r < x.world && r != x.rank && (is_owner || r == owner);
+      v[r] = 0;
+      if (need) {
         v[r] = __hip_atomic_load(mine + (long)r * x.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         all = all && (unsigned)(v[r] >> 32) == seq;
       }
     }
-    if (all) break;
+    if (all) {
+      if (is_owner) {
+        float total = 0.f;
+#pragma unroll
+        for (int r = 0; r < W; ++r)
+          if (r < x.world) total += (r == x.rank) ? own : __uint_as_float((unsigned)v[r]);   // rank order
+        result = old - lr * total;
+        const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(result);
+#pragma unroll
+        for (int r = 0; r < W; ++r)
+          if (r < x.world && r != x.rank)
+            __hip_atomic_store(x.inbox[r] + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+#pragma unroll
+        for (int r = 0; r < W; ++r) result = (r == owner) ? __uint_as_float((unsigned)v[r]) : result;
+      }
+      break;
+    }
     if ((spin & 63u) == 0u) {
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
@@ -731,17 +743,7 @@ __device__ __forceinline__ float xg_exchange_two_phase(const XgParams& x, unsign
     }
     __builtin_amdgcn_s_sleep(1);
   }
-  float total = 0.f;
-#pragma unroll
-  for (int r = 0; r < W; ++r)
-    if (r < x.world) total += (r == x.rank) ? own : __uint_as_float((unsigned)v[r]);
-  const float fresh = old - lr * total;
-  const uint64_t word = ((uint64_t)seq << 32) | (uint64_t)__float_as_uint(fresh);
-#pragma unroll
-  for (int r = 0; r < W; ++r)
-    if (r < x.world && r != x.rank)
-      __hip_atomic_store(x.inbox[r] + slot + (long)x.rank * x.n + e, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return fresh;
+  return result;
 }
 
 // Asynchronous variant (XW < 0): the same per-thread outputs are not swapped but PUSHED -- each gradient element is

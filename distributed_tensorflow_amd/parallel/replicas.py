@@ -737,8 +737,9 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
 def build_replica_trainer(mode: str, **kw):
     cls = {"single": SingleTrainer, "sync": SyncShardTrainer, "towers": TowerTrainer,
-           "async_lockstep": LockstepAsyncRuleTrainer, "async_rccl": AsyncSendRecvTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer, "xgmi2c": XgmiFusedTrainer,
-           "xgmi_async": XgmiAsyncTrainer}[mode]
+           "async_lockstep": LockstepAsyncRuleTrainer, "async": LockstepAsyncRuleTrainer,
+           "async_rccl": AsyncSendRecvTrainer, "xgmi": XgmiTowerTrainer, "xgmi2": XgmiFusedTrainer,
+           "xgmi2c": XgmiFusedTrainer, "xgmi2p": XgmiFusedTrainer, "xgmi_async": XgmiAsyncTrainer}[mode]
     if mode == "xgmi2c":        # the exchange inside the backward launch with 4-byte words
         kw["compact"] = True
     if mode == "xgmi2p":        # ... through the owner of every element (reduce-scatter shaped)

@@ -164,6 +164,30 @@ def test_resident_sync_workers_exchange_inside_the_backward_launch(n_ps, n_w, tr
     assert all(c[-1] < c[0] for c in costs)
 
 
+@pytest.mark.timeout(300)
+def test_more_resident_sync_workers_than_one_gpu_can_keep_spinning_use_the_bounded_exchange(tmp_path):
+    """1 ps + 4 synchronous workers, all on the one GPU (the reference's scenario 2 with more workers): their
+    cross-replica backward launches could not all be resident at once, so the workers agree on the one-kernel
+    exchange after the backward instead of spinning into the exchange's time limit."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.01", "--transport=ipc", "--resident",
+            f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between_sync.py", 1, 4, args, timeout=250)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    steps, accs = [], []
+    for i in range(4):
+        out = res[f"worker{i}"][1]
+        assert "one bounded kernel after the backward" in out and out.rstrip().endswith("Done"), out[-2000:]
+        steps.append([int(v) for v in re.findall(r"Step: (\d+),", out)])
+        accs.append(re.findall(r"Test-Accuracy: ([\d.]+)", out))
+    assert all(s == steps[0] for s in steps) and steps[0][-1] == 2 * 22      # one update per 4 batches, lock step
+    assert all(a == accs[0] for a in accs) and len(accs[0]) == 2            # bit-identical replicas
+
+
 def _single_trainer(double_buffer, pipelined, n=2200, batch=100, chunk=5):
     import numpy as np
 
