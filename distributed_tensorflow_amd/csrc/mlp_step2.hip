@@ -423,7 +423,15 @@ struct BwdParams {
     }                                                                          \
   } while (0)
 
-constexpr int kLdz = 20;   // dz3s row stride: 16-B aligned rows (broadcast b128 reads)
+constexpr int kLdz = 16;   // dz3s row stride = the 16 class slots of a row: the b128 stores of the softmax threads are
+                           // contiguous, a quad of rows read as an MFMA operand (dz3s[(4 w + q) * 16 + i]) covers 64
+                           // consecutive banks, and the broadcast b128 reads of consecutive rows hit distinct slots
+// Row placement of the [128][8] column-tile images a2s / dz2s of the one-launch step: row j lives at row rowswz(j).
+// The correction MFMAs read column r of rows 32 w + 16 g + 4 q + s for (g, q) in {0,1}^2 in one 32-lane group: with
+// plain 8-float rows those four rows share the same 8 banks (bits 2 and 4 of j do not reach the bank number).
+// Folding those two bits into the row's low bits sends the four rows to four different 8-bank blocks; an aligned
+// group of 4 consecutive rows (what the element-wise phases touch per 32 lanes) is only permuted within itself.
+__device__ __forceinline__ int rowswz(int j) { return j ^ (((j >> 2) & 1) | (((j >> 4) & 1) << 1)); }
 
 // Backward with 32(k) x 16(h) tiles of dW1: 175 + 7 + 1 workgroups instead of 100 + 4 + 1, each
 // ingesting ~40 KB instead of ~55 KB (same reasoning as the 8x8 forward tiling: the bytes a CU
@@ -1152,7 +1160,9 @@ struct PipeParams {
 #endif
 constexpr int kPipeNA = DTF_PIPE_NA;
 constexpr int kPipeFwdSlots = 4;      // 8 waves x 4 slots x 2 ranges = 64 macro-steps: K <= 1024
-constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 9 + 8 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
+constexpr int kPipeRed = 72;          // row stride of the cross-wave reduction image: 64 lanes + 8, so that the four
+                                      // accumulator registers of a lane column sit in four different 8-bank blocks
+constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 8 + 8 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
 
 // NSM = full contraction slots per wave (8 waves x 2 ranges x NSM macro-steps of 16 k); TAIL: the
 // K - 256 NSM <= 64 remaining k are contracted by ONE 4-wide step per (wave, range) pair instead of a
@@ -1165,9 +1175,9 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   float* ys = smem + 128 * kLdw;             // [128][17] labels of step t
   float* dz3s = smem + 2 * 128 * kLdw;       // [128][kLdz]
   float* w2t = dz3s + 128 * kLdz;            // [32][17]: rows 0-7 = old W2 rows of the tile's columns
-  float* dz2s = w2t + 32 * kLdw;             // [128][9] dz2 of step t, tile columns
-  float* a2s = dz2s + 128 * 9;               // [128][9] a2 of step t, tile columns
-  float* w2n = a2s + 128 * 9;                // [8 waves][8][16] partial sums of a2^T dz3
+  float* dz2s = w2t + 32 * kLdw;             // [128][8] dz2 of step t, tile columns (rows placed by rowswz)
+  float* a2s = dz2s + 128 * 8;               // [128][8] a2 of step t, tile columns (rows placed by rowswz)
+  float* w2n = a2s + 128 * 8;                // [8 waves][8][16] partial sums of a2^T dz3
   float* w2new = w2n + 8 * 8 * 16;           // [8][17] new W2 rows of the tile's columns
   float* psum = w2new + 8 * kLdw;            // [2][64]
   float* a2t = psum + 128;                   // [8][9] new activations
@@ -1251,7 +1261,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = tid + u * kBwdThreads;
-    a2s[(e >> 3) * 9 + (e & 7)] = ((e >> 3) < M && n0 + (e & 7) < H) ? a2c[u] : 0.f;
+    a2s[rowswz(e >> 3) * 8 + (e & 7)] = ((e >> 3) < M && n0 + (e & 7) < H) ? a2c[u] : 0.f;
   }
   {
     float rl, rc;
@@ -1293,7 +1303,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
       float da = part[0];
 #pragma unroll
       for (int qd = 1; qd < CQ; ++qd) da += part[qd];
-      dz2s[j * 9 + c] = da * dtf_act_bwd(a2s[j * 9 + c], p.act);      // rows >= M: dz3 == 0
+      dz2s[rowswz(j) * 8 + c] = da * dtf_act_bwd(a2s[rowswz(j) * 8 + c], p.act);      // rows >= M: dz3 == 0
     }
   }
   {
@@ -1302,7 +1312,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int j = 4 * (wave + t * kBwdWaves) + q;              // <= 127; rows >= M are zero in both operands
-      const float av = i16 < 8 ? a2s[j * 9 + r8] : 0.f;
+      const float av = i16 < 8 ? a2s[rowswz(j) * 8 + r8] : 0.f;
       wacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dz3s[j * kLdz + i16], wacc, 0, 0, 0);
     }
     if (q < 2) {                                                  // D rows 4q + reg < 8
@@ -1323,16 +1333,16 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   {
     const bool ok = col_ok && jok;
     const unsigned jc = jok ? jb : 0u;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[0], ok ? dz2s[(jc + 0) * 9 + r8] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[1], ok ? dz2s[(jc + 1) * 9 + r8] : 0.f, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[2], ok ? dz2s[(jc + 2) * 9 + r8] : 0.f, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[3], ok ? dz2s[(jc + 3) * 9 + r8] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[0], ok ? dz2s[rowswz(jc + 0) * 8 + r8] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[1], ok ? dz2s[rowswz(jc + 1) * 8 + r8] : 0.f, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[2], ok ? dz2s[rowswz(jc + 2) * 8 + r8] : 0.f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(-lr * ga[3], ok ? dz2s[rowswz(jc + 3) * 8 + r8] : 0.f, acc1, 0, 0, 0);
   }
   const f32x4 acc = acc0 + acc1;
   const float badd = (wave == 0 && g == 0) ? bias : 0.f;
   // (zs / ys, which red aliases, were last read before the two barriers above)
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) red[(wave * 4 + rg) * 64 + lane] = acc[rg] + badd;
+  for (int rg = 0; rg < 4; ++rg) red[(wave * 4 + rg) * kPipeRed + lane] = acc[rg] + badd;
   __syncthreads();
   DTF_STAMP2_AT(lin, 4);
   if (tid < 64) {
@@ -1342,7 +1352,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
     const int rg = r & 3, ln0 = ((r >> 2) << 4) | c, ln1 = (((8 + r) >> 2) << 4) | (8 + c);
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + rg) * 64 + ln0] + red[(w * 4 + rg) * 64 + ln1];
+    for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 + rg) * kPipeRed + ln0] + red[(w * 4 + rg) * kPipeRed + ln1];
     float av = 0.f;
     if (orow < M && ocol < H) {
       av = fast_act(s, p.act);
