@@ -1,10 +1,23 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r2
-timeout -k 10 300 python -u -m pytest tests/test_kernels_gpu.py tests/test_convergence_gpu.py -m gpu -x -q --timeout 250 --timeout-method thread 2>&1 | tail -4
-[ ${PIPESTATUS[0]} -eq 0 ] || exit 1
-for i in 1 2 3; do DTF_BENCH_ASYNC=0 timeout -k 10 120 python bench.py --gpus 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'], d['sec_per_epoch'], d['setup_s'])"; done
+O=$R/gpurun_out/r2/final
+mkdir -p $O
+cd $R
+timeout -k 10 200 python bench.py --gpus 1 > $O/bench_1gpu.json 2> $O/bench_1gpu.err; echo "bench1 rc=$?"
+timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_1gpu_driver_args.json 2>> $O/bench_1gpu.err; echo "bench1 short rc=$?"
+DTF_BENCH_SHARE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --steps 600 --warmup 100 > $O/bench_rehearsal_2ranks_one_gpu.json 2> $O/share2.err; echo "share2 rc=$?"
+DTF_BENCH_SHARE_GPU=1 timeout -k 10 500 python bench.py --gpus 8 --steps 20 --warmup 5 > $O/bench_rehearsal_8ranks_one_gpu.json 2> $O/share8.err; echo "share8 rc=$?"
+DTF_BENCH_SHARE_GPU=1 timeout -k 10 300 python bench.py --gpus 2 --mode ingraph --steps 1100 --warmup 100 > $O/bench_ingraph_2towers_one_gpu.json 2> $O/ingraph.err; echo "ingraph rc=$?"
+for cfg in "tfdist_between.py 1 1 tcp" "tfdist_between.py 1 1 ipc" "tfdist_between.py 1 2 ipc" "tfdist_between.py 2 2 tcp" "tfdist_between.py 2 2 ipc" "tfdist_between.py 1 3 tcp" "tfdist_between.py 1 3 ipc" "tfdist_between_sync.py 1 2 tcp" "tfdist_between_sync.py 1 2 ipc" "tfdist_between_sync.py 2 2 ipc"; do
+  set -- $cfg
+  timeout -k 10 300 python bench/run_cluster.py --script $1 --ps $2 --workers $3 --transport $4 --epochs 6 >> $O/cluster_per_batch.jsonl 2>> $O/cluster.err
+  echo "cluster $cfg rc=$?"
+done
+for cfg in "tfdist_between.py 1 1" "tfdist_between.py 1 2" "tfdist_between.py 2 2" "tfdist_between.py 1 3" "tfdist_between_sync.py 1 2" "tfdist_between_sync.py 2 2" "tfdist_between_sync.py 1 4"; do
+  set -- $cfg
+  timeout -k 10 300 python bench/run_cluster.py --script $1 --ps $2 --workers $3 --transport ipc --epochs 21 -- --resident >> $O/cluster_resident.jsonl 2>> $O/cluster.err
+  echo "resident $cfg rc=$?"
+done
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES --output-format csv -d $R/gpurun_out/r2/pmc_pipe1 -- python3 $R/bench.py --gpus 1 --steps 1100 --warmup 550 > $R/gpurun_out/r2/pmc_pipe1.log 2>&1
-echo "pmc rc=$?"
-cd $R && python bench/summarize_pmc.py gpurun_out/r2/pmc_pipe1 | grep -E "step_pipe|gather_gram"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench1 -- python3 $R/bench.py --gpus 1 --steps 2200 --warmup 550 > $O/kt_bench1.log 2>&1; echo "kt rc=$?"
+f=$(find $O/kt_bench1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_1gpu_kernel_stats.csv && head -12 "$f"

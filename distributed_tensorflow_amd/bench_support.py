@@ -541,7 +541,9 @@ def run_benchmark(args) -> Optional[dict]:
             if rank == 0:
                 store.set("dtf_bench_ingraph_done", "1")
             else:
-                store.wait(["dtf_bench_ingraph_done"])
+                import datetime
+
+                store.wait(["dtf_bench_ingraph_done"], datetime.timedelta(seconds=900))
 
     result = None
     if rank == 0:

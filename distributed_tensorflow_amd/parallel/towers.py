@@ -295,6 +295,11 @@ class InGraphEngine:
     def device(self):
         return self.devices[0]
 
+    @property
+    def engine(self):
+        """Tower 0's engine (cursor, per-step history: read after ``last_loss()``, which waits for the towers)."""
+        return self._loop.engine if self._loop is not None else self.towers[0].engine
+
     def last_loss(self) -> float:
         if self._loop is not None:
             return self._loop.last_loss()

@@ -1,10 +1,14 @@
 #!/usr/bin/env python
-"""In-graph replication: a single client process with one tower per GPU and RCCL gradient
-averaging.  (The reference's tfdist.py is an early between-graph script and its README
+"""In-graph replication: a single client process with one tower per GPU and gradient
+averaging across the towers.  (The reference's tfdist.py is an early between-graph script and its README
 abandons in-graph replication; this script provides that mode.)
 
     python tfdist.py                    # one tower per visible GPU
     python tfdist.py --num_towers 4     # first four GPUs (or CPU towers when no GPU is visible)
+    python tfdist.py --exchange rccl    # RCCL all-reduce driven by a host loop (the library baseline)
+
+``--exchange inbox`` (default on GPUs): every tower has its own stream and hipGraph chunks, and the gradient
+mean is taken inside the towers' backward launches through peer access — one host call per tower per chunk.
 
 Every tower trains on its own shuffled copy of the data with batch_size samples per step,
 so one step consumes num_towers * batch_size samples and makes ONE averaged update.
@@ -15,6 +19,8 @@ import distributed_tensorflow_amd as tf
 from distributed_tensorflow_amd.examples import mnist_mlp
 
 tf.app.flags.DEFINE_integer("num_towers", 0, "number of towers (0: one per visible GPU, at least 1)")
+tf.app.flags.DEFINE_string("exchange", "auto", "gradient mean across towers: inbox (inside the backward launches, "
+                           "hipGraph chunks per tower), rccl (all-reduce, host loop), auto")
 mnist_mlp.define_hparam_flags()
 FLAGS = tf.app.flags.FLAGS
 
@@ -22,7 +28,7 @@ FLAGS = tf.app.flags.FLAGS
 def main(_):
     import torch
 
-    from distributed_tensorflow_amd.parallel.towers import InGraphTowers
+    from distributed_tensorflow_amd.parallel.towers import InGraphEngine, InGraphTowers
 
     mnist = mnist_mlp.load_data(FLAGS)
     print("worker setting up ...", flush=True)
@@ -30,8 +36,18 @@ def main(_):
     n = FLAGS.num_towers or max(n_gpu, 1)
     devices = [f"cuda:{i % n_gpu}" for i in range(n)] if n_gpu else ["cpu"] * n
     begin_time = time.time()
-    towers = InGraphTowers(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
-                           seed=1, act=FLAGS.activation)
+    exchange = FLAGS.exchange
+    if exchange == "auto":
+        # towers that share a GPU must all be resident on it at once to swap gradients inside their launches:
+        # at most two per GPU (the streams of one process share four hardware queues)
+        crowded = n_gpu and max(devices.count(d) for d in devices) > 2
+        exchange = "inbox" if (n_gpu and not crowded and FLAGS.activation == "sigmoid") else "rccl"
+    if exchange == "inbox" and n_gpu:
+        towers = InGraphEngine(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr, seed=1,
+                               chunk=min(50, int(FLAGS.freq)))
+    else:
+        towers = InGraphTowers(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
+                               seed=1, act=FLAGS.activation)
     for i, d in enumerate(devices):
         print(f"tower_{i}: /job:localhost/replica:0/task:0/{d.replace('cuda', 'gpu')}")
     print(towers.describe())
