@@ -184,17 +184,25 @@ def pipe_block_stamps():
     g.replay()
     torch.cuda.synchronize()
     s = stamps.cpu().view(-1, 2)
-    b, f = s[256:256 + 78], s[768:768 + 169]
+    nbk = 175 + 7 + 1                                   # dW1 tiles (25 x 7), dW2 tiles, statistics
+    b, f = s[256:256 + nbk], s[768:768 + 169]
     t0 = int(min(f[:, 0].min(), b[:, 0].min()))
     rel = lambda x: (int(x) - t0) * 10   # noqa: E731
     print("one-launch step, second-to-last launch of a 6-step chunk (ns from the first block start):")
     print("  fwd tiles  start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
-    print("  dW1 tiles  start %5d..%5d   end %5d..%5d" % (rel(b[:70, 0].min()), rel(b[:70, 0].max()), rel(b[:70, 1].min()), rel(b[:70, 1].max())))
-    print("  dW2 tiles + statistics (start/end): " + " ".join("%d/%d" % (rel(b[i, 0]), rel(b[i, 1])) for i in range(70, 78)))
+    print("  dW1 tiles  start %5d..%5d   end %5d..%5d" % (rel(b[:175, 0].min()), rel(b[:175, 0].max()), rel(b[:175, 1].min()), rel(b[:175, 1].max())))
+    print("  dW2 tiles + statistics (start/end): " + " ".join("%d/%d" % (rel(b[i, 0]), rel(b[i, 1])) for i in range(175, nbk)))
     durf = (f[:, 1] - f[:, 0]) * 10
-    durb = (b[:70, 1] - b[:70, 0]) * 10
+    durb = (b[:175, 1] - b[:175, 0]) * 10
     print("  durations: fwd tiles min %d median %d max %d; dW1 tiles min %d median %d max %d" % (
         int(durf.min()), int(durf.median()), int(durf.max()), int(durb.min()), int(durb.median()), int(durb.max())))
+    late = b[:175][b[:175, 0] > b[:175, 0].min() + 100]  # started more than 1 us after the first: second round on their CU
+    if len(late):
+        print("  dW1 tiles of the second round: %d, start %d..%d, end %d..%d" % (
+            len(late), rel(late[:, 0].min()), rel(late[:, 0].max()), rel(late[:, 1].min()), rel(late[:, 1].max())))
+    ends = sorted([rel(x) for x in f[:, 1]] + [rel(x) for x in b[:, 1]])
+    print("  all tiles: 50%% ended by %d, 90%% by %d, 99%% by %d, last %d" % (
+        ends[len(ends) // 2], ends[len(ends) * 9 // 10], ends[len(ends) * 99 // 100], ends[-1]))
 
 
 def pipe_fwd_stamps(block=512 + 30):
@@ -230,6 +238,9 @@ def pipe_fwd_stamps(block=512 + 30):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pipe":
+        pipe_block_stamps()
+        sys.exit(0)
     pipe_fwd_stamps()
     pipe_block_stamps()
     block_stamps()

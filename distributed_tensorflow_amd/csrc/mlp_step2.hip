@@ -1151,6 +1151,8 @@ struct PipeParams {
   int fwd_rows;            // grid rows of forward tiles (0: no forward part in this launch)
   int tiles_n8;
   int tiles_h16;
+  int order;               // 1: one-dimensional grid with the placement below; 0: two-dimensional grid, forward rows first
+  int front;               // order 1: backward tiles placed ahead of the forward tiles
 };
 
 // Backward tiles of the one-launch step are 80 x 16 (NA = 5): forward tiles + backward tiles must not
@@ -1376,10 +1378,45 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
+// Placement (order 1).  The launch has more workgroups than the chip has CUs (169 forward + 183 backward tiles on 256
+// CUs); all of them are resident at once and workgroup i + 256 shares its CU with workgroup i, so both run slower.  The
+// forward tiles and the statistics block are the long ones (the critical path of the step).  The grid is ordered
+//     [front backward tiles] [all forward tiles] [statistics] [the other backward tiles],  front + forward tiles = 255,
+// so that the statistics block and all but a few forward tiles have a CU of their own, nearly every shared CU holds two
+// BACKWARD tiles, and the forward tiles that must share get the last backward tiles (the short dW2 tiles).
 template <int CQ, int NSM, bool TAIL, bool YV2>
 __global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp, int parts) {
   constexpr int kSmem = kPipeFwdSmem > bwd16_smem_floats(kPipeNA) ? kPipeFwdSmem : bwd16_smem_floats(kPipeNA);
   __shared__ __attribute__((aligned(16))) float smem[kSmem];
+  if (pp.order == 1) {
+    const int nf = pp.fwd_rows * pp.tiles_n8;
+    int id = blockIdx.x;
+    if (id >= pp.front && id < pp.front + nf) {   // forward tile of step t+1
+      if (!(parts & 1)) return;
+      const int f = id - pp.front;
+      const int tm = f / pp.tiles_n8, tn = f - tm * pp.tiles_n8;
+      pipe_fwd_body<CQ, NSM, TAIL, YV2>(pp, smem, tn, tm, 512 + f);
+      return;
+    }
+    if (!(parts & 2)) return;
+    const int tiles_k = (pp.b.K + 16 * kPipeNA - 1) / (16 * kPipeNA);
+    const int main_tiles = tiles_k * pp.tiles_h16;
+    // backward tile of step t: dW1 tiles, dW2 tiles, statistics (the last one, placed right after the forward tiles)
+    const int t = id < pp.front ? id : id == pp.front + nf ? main_tiles + pp.tiles_h16 : id - nf - 1;
+    int bx, byb;
+    if (t < main_tiles) {
+      byb = t / pp.tiles_h16;
+      bx = t - byb * pp.tiles_h16;
+    } else if (t < main_tiles + pp.tiles_h16) {
+      byb = tiles_k;
+      bx = t - main_tiles;
+    } else {
+      byb = tiles_k + 1;
+      bx = 0;
+    }
+    bwd_tile16_body<4, CQ, kPipeNA, YV2>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
+    return;
+  }
   const int by = blockIdx.y, bx = blockIdx.x;
   if (by < pp.fwd_rows) {                       // forward tile of step t+1
     if (bx >= pp.tiles_n8 || !(parts & 1)) return;
@@ -1391,6 +1428,7 @@ __global__ __launch_bounds__(kBwdThreads) void step_pipe_kernel(PipeParams pp, i
   bwd_tile16_body<4, CQ, kPipeNA, YV2>(pp.b, smem, bx, byb, byb * pp.tiles_h16 + bx);
 }
 
+int g_pipe_order = 1;   // see step_pipe_kernel (0: the two-dimensional grid, forward rows first)
 int g_pipe_parts = 3;   // timing experiments: 1 = forward tiles only, 2 = backward tiles only (results are then wrong)
 bool g_fwd_tile8 = true;
 long long* g_stamps2 = nullptr;
@@ -1604,6 +1642,7 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
 // Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.
 extern "C" void dtf_debug_set_fwd_tile8(int on) { g_fwd_tile8 = on != 0; }
 extern "C" void dtf_debug_set_pipe_parts(int parts) { g_pipe_parts = parts; }
+extern "C" void dtf_debug_set_pipe_order(int order) { g_pipe_order = order; }
 
 // Profiling hook: device buffer of >= 32 int64 receiving {wall_clock64, clock64}
 // at the phase boundaries of the LAST workgroup of bwd_all; null disables.
@@ -1714,7 +1753,12 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     pp.fwd_rows = (i < n - 1) ? tiles_m8 : 0;
     pp.tiles_n8 = tiles_n8;
     pp.tiles_h16 = tiles_h16;
-    const dim3 grid(tiles_n8 > tiles_h16 ? tiles_n8 : tiles_h16, pp.fwd_rows + tiles_k + 2), block(kBwdThreads);
+    pp.order = g_pipe_order;
+    const int nf = pp.fwd_rows * tiles_n8, nbk = tiles_k * tiles_h16 + tiles_h16 + 1;
+    pp.front = nf >= 255 ? 0 : (255 - nf < nbk - 1 ? 255 - nf : nbk - 1);
+    const dim3 grid = pp.order == 1 ? dim3(nf + nbk)
+                                    : dim3(tiles_n8 > tiles_h16 ? tiles_n8 : tiles_h16, pp.fwd_rows + tiles_k + 2);
+    const dim3 block(kBwdThreads);
     // three full slots + a tail step when K = 768 + (<= 64); the generic form has four slots (K <= 1024)
     const bool tail3 = K >= 768 && K - 768 <= 64;
     const bool fast = cq <= 3 && (C & 1) == 0 && (reinterpret_cast<uintptr_t>(d->y) & 7) == 0;

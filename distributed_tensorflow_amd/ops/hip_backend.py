@@ -180,6 +180,9 @@ def load(required: bool = False) -> Optional[C.CDLL]:
                     raise OSError(f"{_LIB_PATH} was built from other sources: sizeof({mirror.__name__}) is "
                                   f"{lib.dtf_abi_sizeof(which)} there and {C.sizeof(mirror)} here; rebuild with "
                                   f"python -m distributed_tensorflow_amd.build")
+            if os.environ.get("DTF_PIPE_ORDER") is not None:       # tuning experiments (see step_pipe_kernel)
+                lib.dtf_debug_set_pipe_order.argtypes = [C.c_int]
+                lib.dtf_debug_set_pipe_order(int(os.environ["DTF_PIPE_ORDER"]))
             _lib = lib
             return _lib
         except OSError as e:  # pragma: no cover - depends on the machine
