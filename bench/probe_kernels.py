@@ -184,19 +184,21 @@ def pipe_block_stamps():
     g.replay()
     torch.cuda.synchronize()
     s = stamps.cpu().view(-1, 2)
-    nbk = 175 + 7 + 1                                   # dW1 tiles (25 x 7), dW2 tiles, statistics
+    na = int(os.environ.get("DTF_PROBE_NA", "3"))
+    nd = (784 + 16 * na - 1) // (16 * na) * 7          # dW1 tiles
+    nbk = nd + 7 + 1                                    # + dW2 tiles, statistics
     b, f = s[256:256 + nbk], s[768:768 + 169]
     t0 = int(min(f[:, 0].min(), b[:, 0].min()))
     rel = lambda x: (int(x) - t0) * 10   # noqa: E731
     print("one-launch step, second-to-last launch of a 6-step chunk (ns from the first block start):")
     print("  fwd tiles  start %5d..%5d   end %5d..%5d" % (rel(f[:, 0].min()), rel(f[:, 0].max()), rel(f[:, 1].min()), rel(f[:, 1].max())))
-    print("  dW1 tiles  start %5d..%5d   end %5d..%5d" % (rel(b[:175, 0].min()), rel(b[:175, 0].max()), rel(b[:175, 1].min()), rel(b[:175, 1].max())))
-    print("  dW2 tiles + statistics (start/end): " + " ".join("%d/%d" % (rel(b[i, 0]), rel(b[i, 1])) for i in range(175, nbk)))
+    print("  dW1 tiles  start %5d..%5d   end %5d..%5d" % (rel(b[:nd, 0].min()), rel(b[:nd, 0].max()), rel(b[:nd, 1].min()), rel(b[:nd, 1].max())))
+    print("  dW2 tiles + statistics (start/end): " + " ".join("%d/%d" % (rel(b[i, 0]), rel(b[i, 1])) for i in range(nd, nbk)))
     durf = (f[:, 1] - f[:, 0]) * 10
-    durb = (b[:175, 1] - b[:175, 0]) * 10
+    durb = (b[:nd, 1] - b[:nd, 0]) * 10
     print("  durations: fwd tiles min %d median %d max %d; dW1 tiles min %d median %d max %d" % (
         int(durf.min()), int(durf.median()), int(durf.max()), int(durb.min()), int(durb.median()), int(durb.max())))
-    late = b[:175][b[:175, 0] > b[:175, 0].min() + 100]  # started more than 1 us after the first: second round on their CU
+    late = b[:nd][b[:nd, 0] > b[:nd, 0].min() + 100]  # started more than 1 us after the first: second round on their CU
     if len(late):
         print("  dW1 tiles of the second round: %d, start %d..%d, end %d..%d" % (
             len(late), rel(late[:, 0].min()), rel(late[:, 0].max()), rel(late[:, 1].min()), rel(late[:, 1].max())))

@@ -25,6 +25,11 @@ struct DtfHeadLaunch {
 };
 
 int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream);
+// One-kernel evaluation (eval.hip): loss_sum += sum of row losses, correct += rows classified right.
+int dtf_eval_fused_supported(int M, int K, int H, int C);
+int dtf_launch_eval_fused(const float* x, const float* y, int M, int K, int H, int C, int act, const float* W1,
+                          const float* b1, const float* W2, const float* b2, float* loss_sum, int* correct,
+                          hipStream_t stream);
 int dtf_head_grid(int M, int H);
 int dtf_launch_fwd_gemm(const float* xbase, const int* cursor, int bias, int bpe, const float* W,
                         const float* b, float* out, int M, int K, int H, int act, int ksplit,

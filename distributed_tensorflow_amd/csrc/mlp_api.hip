@@ -112,12 +112,18 @@ extern "C" int dtf_mlp_step_grad(const DtfMlpDesc* d, int batch_index, int parit
   return run_step(d, batch_index, parity, DTF_HEAD_GRAD, grad_scale, (hipStream_t)stream);
 }
 
+static int g_eval_fused = 1;
+// 0: evaluation as first-layer GEMM + head kernel (the path for shapes the one-kernel evaluation does not take)
+extern "C" void dtf_debug_set_eval_fused(int on) { g_eval_fused = on; }
+
 extern "C" int dtf_mlp_eval(const float* x, const float* y, int M, int K, int H, int C, int act,
                             const float* W1, const float* b1, const float* W2, const float* b2,
                             float* a2_ws, float* loss_sum, int32_t* correct, void* stream) {
   if (!x || !y || !W1 || !b1 || !W2 || !b2 || !a2_ws || !loss_sum || !correct) return DTF_ERR_NULL;
   if (M <= 0 || K <= 0 || H <= 0 || C <= 0 || C > 16) return DTF_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if (g_eval_fused && dtf_eval_fused_supported(M, K, H, C) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0)
+    return dtf_launch_eval_fused(x, y, M, K, H, C, act, W1, b1, W2, b2, loss_sum, correct, s);
   int rc = dtf_launch_fwd_gemm(x, nullptr, 0, 0, W1, b1, a2_ws, M, K, H, act, 1, s);
   if (rc) return rc;
   DtfHeadLaunch h;

@@ -65,55 +65,10 @@ struct HeadParams {
     }                                                             \
   } while (0)
 
-// 16-lane reductions on the DPP crossbar (a DPP "row" is exactly one 16-lane
-// MFMA column group): quad xor-1, quad xor-2, half-row mirror, row mirror.
-// Full-rate VALU moves instead of ds_bpermute round trips through the LDS.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
-}
-constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141; // lane i <-> 7-i within 8
-constexpr int kDppRowMirror = 0x140;  // lane i <-> 15-i within 16
-
-__device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, dpp_f<kDppXor1>(v));
-  v = fmaxf(v, dpp_f<kDppXor2>(v));
-  v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
-  v = fmaxf(v, dpp_f<kDppRowMirror>(v));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-  v += dpp_f<kDppXor1>(v);
-  v += dpp_f<kDppXor2>(v);
-  v += dpp_f<kDppHalfMirror>(v);
-  v += dpp_f<kDppRowMirror>(v);
-  return v;
-}
-// argmax with ties resolved to the smallest index (tf.argmax behaviour).  The
-// comparison is a total order, so every lane of the group ends with the same pair.
-template <int CTRL>
-__device__ __forceinline__ void argmax_step(float& v, int& idx) {
-  const float ov = dpp_f<CTRL>(v);
-  const int oi = dpp_i<CTRL>(idx);
-  if (ov > v || (ov == v && oi < idx)) {
-    v = ov;
-    idx = oi;
-  }
-}
-__device__ __forceinline__ int group16_argmax(float v, int idx) {
-  argmax_step<kDppXor1>(v, idx);
-  argmax_step<kDppXor2>(v, idx);
-  argmax_step<kDppHalfMirror>(v, idx);
-  argmax_step<kDppRowMirror>(v, idx);
-  return idx;
-}
+// 16-lane reductions on the DPP crossbar (dtf_common.h): a DPP "row" is exactly one 16-lane MFMA column group.
+__device__ __forceinline__ float group16_max(float v) { return row16_max(v); }
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
+__device__ __forceinline__ int group16_argmax(float v, int idx) { return row16_argmax(v, idx); }
 // Sum over the four 16-lane groups of a wave (rows of one MFMA tile).
 __device__ __forceinline__ float across_groups_sum(float v) {
   v += __shfl_xor(v, 16);
@@ -458,7 +413,7 @@ int pick_rows(int M, int H) {
   return R;
 }
 
-bool g_attr_set = false;
+unsigned long long g_attr_set = 0;
 long long* g_stamps = nullptr;   // device buffer of 16 {wall, cycle} pairs, or null
 
 }  // namespace
@@ -476,11 +431,13 @@ int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream) {
   if (lds > 160 * 1024) return DTF_ERR_UNSUPPORTED;
   const int grid = (a.M + R - 1) / R;
   if (a.mode == DTF_HEAD_FUSED && grid != 1) return DTF_ERR_UNSUPPORTED;
-  if (!g_attr_set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
+  if (dev >= 64 || !((g_attr_set >> dev) & 1ull)) {   // one bit per device: the attribute belongs to the device's copy
     if (hipFuncSetAttribute((const void*)mlp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return DTF_ERR_LAUNCH;
-    g_attr_set = true;
+    if (dev < 64) g_attr_set |= 1ull << dev;
   }
   HeadParams p;
   p.zin = a.zin; p.pre_act = a.pre_act; p.zero_zin = a.zero_zin;

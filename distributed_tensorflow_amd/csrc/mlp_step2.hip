@@ -74,45 +74,6 @@ __device__ __forceinline__ f32x4 ld4_c(const float* __restrict__ p, int idx, boo
   return *reinterpret_cast<const f32x4*>(p + (ok ? idx : 0));
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
-}
-constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kHalfMirror = 0x141, kRowMirror = 0x140;
-
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_f<kXor1>(v));
-  v = fmaxf(v, dpp_f<kXor2>(v));
-  v = fmaxf(v, dpp_f<kHalfMirror>(v));
-  return fmaxf(v, dpp_f<kRowMirror>(v));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_f<kXor1>(v);
-  v += dpp_f<kXor2>(v);
-  v += dpp_f<kHalfMirror>(v);
-  return v + dpp_f<kRowMirror>(v);
-}
-template <int CTRL>
-__device__ __forceinline__ void argmax_step(float& v, int& idx) {
-  const float ov = dpp_f<CTRL>(v);
-  const int oi = dpp_i<CTRL>(idx);
-  if (ov > v || (ov == v && oi < idx)) {
-    v = ov;
-    idx = oi;
-  }
-}
-__device__ __forceinline__ int row16_argmax(float v, int idx) {  // ties -> smallest index
-  argmax_step<kXor1>(v, idx);
-  argmax_step<kXor2>(v, idx);
-  argmax_step<kHalfMirror>(v, idx);
-  argmax_step<kRowMirror>(v, idx);
-  return idx;
-}
 
 // ---------------------------------------------------------------------------
 // Forward: 16x16 output tile per workgroup, 16 waves split K.
@@ -1155,13 +1116,14 @@ struct PipeParams {
   int front;               // order 1: backward tiles placed ahead of the forward tiles
 };
 
-// Backward tiles of the one-launch step are 80 x 16 (NA = 5): forward tiles + backward tiles must not
-// exceed the CUs of the chip, or some CUs run two workgroups and finish last (169 + 78 <= 256).
+// Backward dW1 tiles of the one-launch step are 48 x 16 (NA = 3): 17 x 7 + 7 dW2 tiles + the statistics block = 127
+// workgroups next to the 169 forward tiles.  With the placement of step_pipe_kernel all forward tiles and the statistics
+// block then have a CU of their own and 40 CUs hold two backward tiles.  Measured per step on one box: NA = 2 (183
+// backward workgroups, 10 forward tiles share a CU) 8.24 us, NA = 3 8.10 us, NA = 4 8.12 us.
 #ifndef DTF_PIPE_NA
-#define DTF_PIPE_NA 2
+#define DTF_PIPE_NA 3
 #endif
 constexpr int kPipeNA = DTF_PIPE_NA;
-constexpr int kPipeFwdSlots = 4;      // 8 waves x 4 slots x 2 ranges = 64 macro-steps: K <= 1024
 constexpr int kPipeRed = 72;          // row stride of the cross-wave reduction image: 64 lanes + 8, so that the four
                                       // accumulator registers of a lane column sit in four different 8-bank blocks
 constexpr int kPipeFwdSmem = 2 * 128 * kLdw + 128 * kLdz + 32 * kLdw + 2 * 128 * 8 + 8 * 8 * 16 + 8 * kLdw + 128 + 80 + 16;
@@ -1378,7 +1340,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
-// Placement (order 1).  The launch has more workgroups than the chip has CUs (169 forward + 183 backward tiles on 256
+// Placement (order 1).  The launch has more workgroups than the chip has CUs (169 forward + 127 backward tiles on 256
 // CUs); all of them are resident at once and workgroup i + 256 shares its CU with workgroup i, so both run slower.  The
 // forward tiles and the statistics block are the long ones (the critical path of the step).  The grid is ordered
 //     [front backward tiles] [all forward tiles] [statistics] [the other backward tiles],  front + forward tiles = 255,

@@ -180,6 +180,35 @@ def test_eval_matches_reference():
     assert abs(acc - float(wa)) < 1e-4
 
 
+@pytest.mark.parametrize("M,K,H,act", [(10000, 784, 100, 0), (77, 784, 100, 1), (48, 64, 112, 0), (1000, 260, 37, 0)])
+def test_one_kernel_evaluation_matches_reference_and_two_kernel_path(M, K, H, act):
+    """eval.hip against the fp64 oracle and against the first-layer GEMM + head kernel pair it replaces."""
+    import ctypes as C
+    lib = hb.require()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.rand(M, K, generator=g).to(DEV)
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (M,), generator=g), 10).float().to(DEV)
+    W1 = (torch.randn(K, H, generator=g) * 0.1).to(DEV)
+    b1 = torch.randn(H, generator=g).to(DEV)
+    W2 = torch.randn(H, 10, generator=g).to(DEV)
+    b2 = torch.randn(10, generator=g).to(DEV)
+    ws = torch.empty(M * H, device=DEV)
+    out = {}
+    lib.dtf_debug_set_eval_fused.argtypes = [C.c_int]
+    try:
+        for fused in (1, 0):
+            lib.dtf_debug_set_eval_fused(fused)
+            ls, cc = torch.zeros(1, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+            hb.mlp_eval(x, y, W1, b1, W2, b2, act, ws, ls, cc)
+            out[fused] = (float(ls.item()) / M, int(cc.item()))
+    finally:
+        lib.dtf_debug_set_eval_fused(1)
+    wl, wa = ref.mlp_loss_acc(x.double(), y.double(), W1.double(), b1.double(), W2.double(), b2.double(), act)
+    for fused in (1, 0):
+        assert abs(out[fused][0] - float(wl)) < 1e-4 * max(1.0, float(wl)), (fused, out, float(wl))
+        assert abs(out[fused][1] - round(float(wa) * M)) <= 1, (fused, out, float(wa) * M)
+
+
 def test_log_zero_edge_case_is_finite(step_path):
     # saturated logits: the reference's log(softmax) would produce -inf * 0 = NaN
     eng = _engine(DEV, scale=1.0)
