@@ -341,7 +341,13 @@ class DeviceDataset:
             torch.index_select(self.y, 0, perm, out=s["y"])
             if self._with_gram:
                 self._fill_gram(s)
-        self._stage_perm()          # next epoch's order: host work and copy happen behind the queued GPU work
+        # next epoch's order: drawn on the host and copied behind GPU work.  In place, the draw (0.3 ms of CPU time
+        # for 55,000 rows) is left to stage_ahead(), which a trainer calls AFTER it has queued the steps that follow
+        # the reshuffle, so the device is not kept waiting for them.
+        if self.double_buffer or self.device.type != "cuda":
+            self._stage_perm()
+        else:
+            self._perm_due = True
 
     def _fused_refresh(self) -> bool:
         """Whether the hand-written gather + Gram kernel (csrc/gram.hip) covers this set's shape."""
@@ -358,11 +364,18 @@ class DeviceDataset:
             ld = (b + 15) // 16 * 16
             s["gram"] = torch.zeros((nb - 1, b, ld), dtype=torch.float32, device=self.device)
 
+    def stage_ahead(self):
+        """Draw and upload the next epoch's order now, if that is still to do (cheap to call after every chunk)."""
+        if getattr(self, "_perm_due", False):
+            self._perm_due = False
+            self._stage_perm()
+
     def _take_perm(self) -> torch.Tensor:
         """The permutation of this epoch, already on the device: it is drawn and copied (pinned, asynchronous)
         right after the previous one was used, so a reshuffle neither waits for the host nor drains the
         stream with a blocking copy."""
         if self._staged_perm is None:
+            self._perm_due = False
             self._stage_perm()
         perm = self._staged_perm
         self._staged_perm = None

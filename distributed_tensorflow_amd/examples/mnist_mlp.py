@@ -149,8 +149,28 @@ def run_resident_loop(trainer, mnist, flags, writer=None, begin_time: Optional[f
     batch_count = trainer.engine.batches_per_epoch
     start_time = time.time()
     total, cost, acc, epoch_times = 0, float("nan"), float("nan"), []
+    want_history = writer is not None and bool(flags.summaries)
+    pipelined = hasattr(trainer, "fetch_window_async")
+    state = {"start": start_time, "cost": cost}
+
+    def emit(pending):
+        """Print (and log) a finished window; with a pipelined trainer the NEXT window is already running."""
+        handle, epoch_, last_i, first_, k_ = pending
+        if pipelined:
+            cost_, losses, accs, gstep = handle.result()
+            step = int(round(gstep)) - 1         # value a fetch in the last run of the window would have seen
+        else:
+            cost_, step, losses, accs = handle
+        if want_history:
+            steps = np.arange(step - k_ + 1, step + 1)
+            writer.add_scalar_series(steps, ["cost", "accuracy"], np.stack([losses.numpy(), accs.numpy()], 1))
+        now = time.time()
+        print(progress_line(step, epoch_, last_i, batch_count, cost_, now - state["start"], freq), flush=True)
+        state["start"], state["cost"] = now, cost_
+
     for epoch in range(int(flags.epochs)):
         i = 0
+        pending = None
         while i < batch_count:
             k = min(freq, batch_count - i)
             if flags.max_steps:
@@ -159,17 +179,22 @@ def run_resident_loop(trainer, mnist, flags, writer=None, begin_time: Optional[f
             trainer.run_steps(k)
             i += k
             total += k
-            cost = trainer.last_loss()          # the only host sync of the window
-            step = step_of(trainer) - 1          # value a fetch in the last run of the window would have seen
-            if writer is not None and flags.summaries:
-                losses, accs = trainer.engine.history(first, k)
-                steps = np.arange(step - k + 1, step + 1)
-                writer.add_scalar_series(steps, ["cost", "accuracy"], np.stack([losses.numpy(), accs.numpy()], 1))
-            elapsed = time.time() - start_time
-            start_time = time.time()
-            print(progress_line(step, epoch, i - 1, batch_count, cost, elapsed, freq), flush=True)
+            if pipelined:
+                # the window's cost, step counter and history are copied behind it; they are read (one wait per
+                # window, as the reference's per-step fetch implies) only after the next window has been launched
+                handle = trainer.fetch_window_async(first, k, want_history)
+            else:
+                cost_now = trainer.last_loss()  # the only host sync of the window
+                losses, accs = trainer.engine.history(first, k) if want_history else (None, None)
+                handle = (cost_now, step_of(trainer) - 1, losses, accs)
+            if pending is not None:
+                emit(pending)
+            pending = (handle, epoch, i - 1, first, k)
             if flags.max_steps and total >= int(flags.max_steps):
                 break
+        if pending is not None:
+            emit(pending)
+        cost = state["cost"]
         _, acc = trainer.evaluate(test_x, test_y)
         print("Test-Accuracy: %2.2f" % acc)
         epoch_times.append(time.time() - begin_time)

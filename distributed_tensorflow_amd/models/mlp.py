@@ -34,6 +34,33 @@ from ..ops import hip_backend as hb
 from ..ops import reference as ref
 
 
+class _Fetched:
+    """A window's results that are already on the host."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
+class _PendingFetch:
+    """A window's results on their way into a pinned staging row (see MLPEngine.fetch_window_async)."""
+
+    def __init__(self, slot, event, count, has_extra):
+        self._slot, self._event, self._count, self._has_extra = slot, event, count, has_extra
+        self._value = None
+
+    def result(self):
+        if self._value is None:
+            self._event.synchronize()
+            buf, n = self._slot["buf"], self._count
+            self._value = (float(buf[0]), buf[2:2 + n].clone() if n else None,
+                           buf[2 + n:2 + 2 * n].clone() if n else None, float(buf[1]) if self._has_extra else None)
+            self._slot["free"] = True
+        return self._value
+
+
 class MLPEngine:
     PARAM_NAMES = ("W1", "b1", "W2", "b2")
 
@@ -422,3 +449,42 @@ class MLPEngine:
 
     def last_loss(self) -> float:
         return float(self.loss_hist[self._slot(self._host_cursor - 1)].item())
+
+    def fetch_window_async(self, first_step: int, count: int, want_history: bool = False, extra=None):
+        """Queue the copies of a finished window's results behind it and return a handle; ``handle.result()`` waits
+        for those copies only, so the caller can launch the next window first and read this one while it runs.
+
+        result() -> (cost of the window's last step, per-step losses, per-step accuracies, extra value) with the two
+        series None unless ``want_history``; ``extra``: an optional one-element device tensor (the step counter)
+        copied at the same point of the stream."""
+        last = self._slot(first_step + count - 1)
+        if not self.on_gpu:
+            losses = accs = None
+            if want_history:
+                losses, accs = self.history(first_step, count)
+            return _Fetched((float(self.loss_hist[last]), losses, accs, None if extra is None else float(extra.item())))
+        pool = getattr(self, "_fetch_pool", None)
+        if pool is None:
+            pool = self._fetch_pool = []
+        # a pinned staging row per window in flight (reused once its copy has been read)
+        n = 2 + (2 * count if want_history else 0)
+        slot = next((b for b in pool if b["free"] and b["buf"].numel() >= n), None)
+        if slot is None:
+            slot = {"buf": torch.empty(max(n, 2 + 2 * min(self.hist_cap, self.batches_per_epoch)),
+                                       dtype=torch.float32).pin_memory(), "free": True}
+            pool.append(slot)
+        slot["free"] = False
+        buf = slot["buf"]
+        buf[0:1].copy_(self.loss_hist[last:last + 1], non_blocking=True)
+        if extra is not None:
+            buf[1:2].copy_(extra.reshape(1).to(torch.float32), non_blocking=True)
+        if want_history:
+            if count > min(self.hist_cap, self.batches_per_epoch):
+                raise ValueError("history window larger than the ring")
+            idx = torch.tensor([self._slot(s) for s in range(first_step, first_step + count)], dtype=torch.long)
+            idx = idx.to(self.device, non_blocking=True)
+            buf[2:2 + count].copy_(self.loss_hist[idx], non_blocking=True)
+            buf[2 + count:2 + 2 * count].copy_(self.acc_hist[idx], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return _PendingFetch(slot, ev, count if want_history else 0, extra is not None)

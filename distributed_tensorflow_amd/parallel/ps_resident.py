@@ -181,6 +181,14 @@ class PsResidentTrainer(_BaseTrainer):
     def global_step_value(self) -> int:
         return self.store.global_step()
 
+    def fetch_window_async(self, first_step: int, count: int, want_history: bool = False):
+        # the step counter lives on its owner shard and is read through the store: fetched at once
+        from ..models.mlp import _Fetched
+
+        cost = self.last_loss()
+        losses, accs = self.engine.history(first_step, count) if want_history else (None, None)
+        return _Fetched((cost, losses, accs, float(self.global_step_value())))
+
     def describe(self) -> str:
         push = ("forward -> backward that pushes -lr*g per element into the owning shard (float atomics)"
                 if self._push_desc is not None else "2 launches -> one-sided SGD push")

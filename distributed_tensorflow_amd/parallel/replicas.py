@@ -197,12 +197,19 @@ class _BaseTrainer:
                 with span("chunk_eager", steps=k):
                     self._run_eager(cur % bpe, k)
             self.steps_done += k
+            if hasattr(self.ds, "stage_ahead"):
+                self.ds.stage_ahead()       # host work for the NEXT reshuffle, behind the work queued above
 
     def evaluate(self, x, y):
         return self.engine.evaluate(x, y)
 
     def last_loss(self) -> float:
         return self.engine.last_loss()
+
+    def fetch_window_async(self, first_step: int, count: int, want_history: bool = False):
+        """Results of the window just run, without waiting for it: see MLPEngine.fetch_window_async.  The fourth
+        value of ``result()`` is the shared step counter as it stood right after the window."""
+        return self.engine.fetch_window_async(first_step, count, want_history, extra=self.global_step)
 
     def global_step_value(self) -> int:
         return int(round(float(self.global_step.item())))
