@@ -243,6 +243,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pipe":
         pipe_block_stamps()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fwd":
+        for blk in (512 + 30, 512 + 100, 512 + 160):
+            pipe_fwd_stamps(blk)
+        sys.exit(0)
     pipe_fwd_stamps()
     pipe_block_stamps()
     block_stamps()

@@ -55,6 +55,8 @@ typedef struct DtfPipeDesc {
                               //   zero for i >= B
   int32_t gram_ld;            // multiple of 16, B <= gram_ld <= 128
   int32_t reserved;
+  float* w1t;                 // [2][hidden][in_dim]: W1 transposed, one image per parameter set (kept by the chunk's
+                              //   own launches; contents between chunks are scratch)
 } DtfPipeDesc;
 
 // `batch_index` = mini-batch of the resident set (added to *cursor when a

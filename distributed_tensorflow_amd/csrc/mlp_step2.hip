@@ -346,6 +346,10 @@ struct BwdParams {
   const float* W2r;       // W2 to READ (shadow in fused mode, live otherwise) [H,C]
   const float* b2r;       // b2 to READ [C]
   float* oW1;             // fused: W1 to WRITE; grad: gW1
+  // One-launch step: between the first and the last step of a chunk W1 lives TRANSPOSED ([H][K]) only -- the form the
+  // forward tiles read (a tile's 8 columns are 8 contiguous rows, a lane's four k one 16-byte load).
+  const float* rW1T;      // old values, transposed (null: read rW1)
+  float* oW1T;            // where the new values go, transposed (null: store oW1)
   float* ob1;             // fused: b1 to WRITE; grad: gb1
   const float* rW1;       // fused: W1 holding the OLD values (== oW1 for an in-place update); grad: gW1
   const float* rb1;       // same for b1
@@ -512,7 +516,26 @@ __device__ __forceinline__ f32x4 smax_dz3(const SmaxIn& in, int tid, int M, int 
 }
 
 // NA = 16-row sub-tiles of dW1 per workgroup (tile = 16 NA rows x 16 columns).
-constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * 64 > 2 * 128 * kLdw ? 8 * NA * 4 * 64 : 2 * 128 * kLdw; }
+// Row stride of the backward tiles' cross-wave reduction image: 64 lanes + 4.  Rows are written lane by lane; with
+// out_map's transposed form a wave reads (4 registers) x (4 lane groups) x (4 columns) = rows r..r+3 at lanes
+// 16 g + c..c+3, i.e. banks 4 r + 16 g + c: 64 different ones.
+constexpr int kBwdRed = 68;
+constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * kBwdRed > 2 * 128 * kLdw ? 8 * NA * 4 * kBwdRed : 2 * 128 * kLdw; }
+// Output element o of a backward tile -> (16-row sub-tile, accumulator register, lane) of the reduction image.
+// Plain: a wave takes one (sub-tile, register) image, lane by lane (a store covers 4 rows x 64 bytes of W1[K][H]).
+// Transposed: o = ((sub * 16 + column) * 4 + lane group) * 4 + register, so that consecutive threads walk k first.
+__device__ __forceinline__ void out_map(int o, bool transposed, int& sub, int& reg, int& ln) {
+  if (transposed) {
+    reg = o & 3;
+    const int c = o >> 4;
+    ln = 16 * ((o >> 2) & 3) + (c & 15);
+    sub = c >> 4;
+  } else {
+    sub = o >> 8;
+    reg = (o >> 6) & 3;
+    ln = o & 63;
+  }
+}
 constexpr int bwd16_smem_floats(int NA) { return bwd16_red_floats(NA) + 128 * kLdz + 32 * kLdw + 256 + 64; }
 
 // (bx, by) = position in the backward part of the grid, `lin` = linear id for the profiling stamps.
@@ -799,20 +822,24 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  // output elements of this thread after the cross-wave reduction: o = tid + 512 u -> (sub-tile, register, lane)
+  // output elements of this thread after the cross-wave reduction: o = tid + 512 u -> (sub-tile, register, lane).
+  // With W1 transposed the map is chosen so that 16 consecutive threads hold 16 consecutive k of one column (64
+  // contiguous bytes of a W1T row) and the 64 threads of a wave four neighbouring columns (out_map).
   constexpr int kOuts = (256 * NA + kBwdThreads - 1) / kBwdThreads;
+  const bool tmap = !XG && p.rW1T != nullptr;
   unsigned wo[kOuts];
 #pragma unroll
   for (int u = 0; u < kOuts; ++u) {
-    const int o = tid + u * kBwdThreads;
-    const int trow = 16 * (o >> 8) + 4 * ((o & 63) >> 4) + ((o >> 6) & 3), tcol = o & 15;
-    wo[u] = umin_(__umul24(k0 + trow, H) + h0 + tcol, (unsigned)K * H - 1) * 4u;
+    int o_sub, o_reg, o_ln;
+    out_map(tid + u * kBwdThreads, tmap, o_sub, o_reg, o_ln);
+    const int trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, tcol = o_ln & 15;
+    wo[u] = umin_(tmap ? __umul24(h0 + tcol, K) + k0 + trow : __umul24(k0 + trow, H) + h0 + tcol, (unsigned)K * H - 1) * 4u;
   }
   const unsigned b1o = umin_(h0 + (tid & 15), H - 1) * 4u;
   __builtin_amdgcn_sched_barrier(0);
   float wold[kOuts];     // fused: old weights; gradient mode: valid locations, ignored
 #pragma unroll
-  for (int u = 0; u < kOuts; ++u) wold[u] = ld_ub(p.rW1, wo[u]);
+  for (int u = 0; u < kOuts; ++u) wold[u] = ld_ub(tmap ? p.rW1T : p.rW1, wo[u]);
   const float b1old = ld_ub(p.rb1, b1o);
   // the step counter travels with the other old values instead of a dependent load + store at the
   // very end of the statistics block (which finishes last); any valid address when there is none
@@ -895,7 +922,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
 #pragma unroll
     for (int sa = 0; sa < NA; ++sa)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) red[(wave * 4 * NA + 4 * sa + g) * 64 + lane] = acc[sa][g];
+      for (int g = 0; g < 4; ++g) red[(wave * 4 * NA + 4 * sa + g) * kBwdRed + lane] = acc[sa][g];
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
     if constexpr (XG) {
@@ -906,7 +933,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * 64 + o_ln];
+        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + o_ln];
         xown[0] = gs * s;
         if (is_main) {
           const int orow = k0 + o_trow, ocol = h0 + o_tcol;
@@ -947,14 +974,21 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     for (int u = 0; u < kOuts; ++u) {
       const int o = tid + u * kBwdThreads;
       if (o < 256 * NA) {
-        const int o_sub = o >> 8, o_reg = (o >> 6) & 3, o_ln = o & 63;
+        int o_sub, o_reg, o_ln;
+        out_map(o, tmap, o_sub, o_reg, o_ln);
         const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * 64 + o_ln];
+        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + o_ln];
         if (is_main) {
           const int orow = k0 + o_trow, ocol = h0 + o_tcol;
-          if (orow < K && ocol < H) p.oW1[(long)orow * H + ocol] = p.fused ? wold[u] - lr * s : gs * s;
+          if (orow < K && ocol < H) {
+            const float v = p.fused ? wold[u] - lr * s : gs * s;
+            if (p.oW1T != nullptr)
+              p.oW1T[(long)ocol * K + orow] = v;
+            else
+              p.oW1[(long)orow * H + ocol] = v;
+          }
         } else if (o_sub == 0) {
           const int h = h0 + o_trow;
           if (h < H && o_tcol < C) p.oW2[h * C + o_tcol] = p.fused ? w2t[o_trow * kLdw + o_tcol] - lr * s : gs * s;
@@ -1102,8 +1136,8 @@ __global__ __launch_bounds__(kBwdThreads) void bwd_tile16_xg_kernel(BwdParams p,
 // is dz2 (from LDS).  W2new rows of the tile (for the logit partials) are rebuilt locally too.
 struct PipeParams {
   BwdParams b;             // backward part (step t); also carries the shapes and common inputs
-  const float* W1r;        // forward part: parameters before step t's update
-  const float* b1r;
+  const float* W1Tr;       // forward part: parameters before step t's update; W1 TRANSPOSED ([H][K]): the 8 columns
+  const float* b1r;        //   of a forward tile are 8 contiguous rows of it, and a lane's four k are one 16-byte load
   long next_index;         // batch t+1
   const float* gram;       // G1 of the pair (t, t+1): [M][gram_ld], zero beyond column M
   int gram_ld;             // multiple of 16
@@ -1188,7 +1222,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- group 3: the main operands (x' rows, old W1 columns): needed last, issued last ---------------------
-  unsigned xo[NSM], wo[NSM][4];
+  unsigned xo[NSM], wo[NSM];
   bool kok[NSM];
 #pragma unroll
   for (int j = 0; j < NSM; ++j) {
@@ -1196,26 +1230,23 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
     kok[j] = kb < (unsigned)K;
     const unsigned kbc = kok[j] ? kb : K - 4;
     xo[j] = (__umul24(row_c, K) + kbc) * 4u;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wo[j][s] = (__umul24(kbc + s, H) + col_c) * 4u;
+    wo[j] = (__umul24(col_c, K) + kbc) * 4u;
   }
   const unsigned kt = 256u * NSM + 4u * (2u * wave + g) + q;        // tail: one k per lane
   const bool kt_ok = TAIL && kt < (unsigned)K;
   const unsigned ktc = kt_ok ? kt : K - 1;
-  const unsigned xto = (__umul24(row_c, K) + ktc) * 4u, wto = (__umul24(ktc, H) + col_c) * 4u;
+  const unsigned xto = (__umul24(row_c, K) + ktc) * 4u, wto = (__umul24(col_c, K) + ktc) * 4u;
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 a[NSM];
-  float bv[NSM][4];
+  f32x4 a[NSM], bv[NSM];
 #pragma unroll
   for (int j = 0; j < NSM; ++j) {
     a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Xn) + xo[j]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(pp.W1r, wo[j][s]);
+    bv[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(pp.W1Tr) + wo[j]);
   }
   float at = 0.f, bt = 0.f;
   if (TAIL) {
     at = ld_ub(Xn, xto);
-    bt = ld_ub(pp.W1r, wto);
+    bt = ld_ub(pp.W1Tr, wto);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1451,6 +1482,8 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
   p.W2r = fused ? d->shadow : d->W2;
   p.b2r = fused ? d->shadow + H * C : d->b2;
   p.oW1 = fused ? d->W1 : d->gW1;
+  p.oW1T = nullptr;
+  p.rW1T = nullptr;
   p.ob1 = fused ? d->b1 : d->gb1;
   p.oW2 = fused ? d->W2 : d->gW2;
   p.ob2 = fused ? d->b2 : d->gb2;
@@ -1615,6 +1648,17 @@ extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block
 // {start, end} wall-clock stamps of the next two-launch steps; null disables.
 extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }
 
+// dst[c][r] = src[r][c] for a [rows][cols] matrix (32 x 32 tiles through LDS; block (32, 8)).
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (r0 + i < rows && c0 + threadIdx.x < cols) tile[i][threadIdx.x] = src[(long)(r0 + i) * cols + c0 + threadIdx.x];
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8)
+    if (c0 + i < cols && r0 + threadIdx.x < rows) dst[(long)(c0 + i) * rows + r0 + threadIdx.x] = tile[threadIdx.x][i];
+}
+
 __global__ void zero_floats_kernel(float* p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -1641,15 +1685,15 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
   if (!dtf_mlp_chunk_pipelined_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
   if (!d->x || !d->y || !d->W1 || !d->b1 || !d->W2 || !d->b2 || !d->z2 || !d->lr) return DTF_ERR_NULL;
-  if (!q->tW1 || !q->tb1 || !q->tW2 || !q->tb2 || !q->a2b || !q->zws3 || !q->gram) return DTF_ERR_NULL;
+  if (!q->tW1 || !q->tb1 || !q->tW2 || !q->tb2 || !q->a2b || !q->zws3 || !q->gram || !q->w1t) return DTF_ERR_NULL;
   if (n < 1 || first_batch < 0 || first_batch + n > d->batches_per_epoch) return DTF_ERR_SHAPE;
   if (q->gram_ld < B || (q->gram_ld & 15) || q->gram_ld > 128) return DTF_ERR_SHAPE;
   const int R = ((B + 15) / 16) * 16;
   const int tiles_m8 = (B + 7) / 8, tiles_n8 = (H + 7) / 8, tiles_h16 = (H + 15) / 16;
   const int tiles_k = (K + 16 * kPipeNA - 1) / (16 * kPipeNA);
   const int cq = (C + 3) / 4;
-  struct Set { float *W1, *b1, *W2, *b2; };
-  const Set canon{d->W1, d->b1, d->W2, d->b2}, twin{q->tW1, q->tb1, q->tW2, q->tb2};
+  struct Set { float *W1, *b1, *W2, *b2, *W1T; };
+  const Set canon{d->W1, d->b1, d->W2, d->b2, q->w1t}, twin{q->tW1, q->tb1, q->tW2, q->tb2, q->w1t + (size_t)K * H};
   float* a2buf[2] = {d->z2, q->a2b};
   float* zw[3] = {q->zws3, q->zws3 + 2048, q->zws3 + 4096};
   // (a kernel, not hipMemsetAsync: inside a stream capture the memset was observed to take effect at
@@ -1679,6 +1723,9 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
 #undef DTF_F0_ARGS
   }
   Set cur = start_twin ? twin : canon;
+  if (n > 1) {          // the transposed image the first one-launch forward reads; every later one is stored by a backward
+    hipLaunchKernelGGL(transpose_kernel, dim3((K + 31) / 32, (H + 31) / 32), dim3(32, 8), 0, stream, d->W1, cur.W1T, K, H);
+  }
   for (int i = 0; i < n; ++i) {
     const Set nxt = (cur.W1 == canon.W1) ? twin : canon;
     const long bi = first_batch + i;
@@ -1692,6 +1739,8 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     p.W2r = cur.W2; p.b2r = cur.b2;
     p.rW1 = cur.W1; p.rb1 = cur.b1;
     p.oW1 = nxt.W1; p.ob1 = nxt.b1; p.oW2 = nxt.W2; p.ob2 = nxt.b2;
+    p.rW1T = n > 1 ? cur.W1T : nullptr;
+    p.oW1T = i + 1 < n ? nxt.W1T : nullptr;       // the last step leaves W1 in the caller's tensor
     p.zclear = zw[(i + 2) % 3];
     p.zclear_n = R * 16;
     p.lr = d->lr;
@@ -1706,7 +1755,7 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     p.stamps = observed ? g_stamps2 : nullptr;
     p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h16 + tiles_h16 + 1 + g_stamp_block;
     p.bs = BlockStamps{g_block_stamps && observed ? g_block_stamps + 2 * 256 : nullptr};
-    pp.W1r = cur.W1; pp.b1r = cur.b1;
+    pp.W1Tr = cur.W1T; pp.b1r = cur.b1;
     pp.next_index = bi + 1;
     pp.gram = q->gram + (size_t)bi * B * q->gram_ld;
     pp.gram_ld = q->gram_ld;

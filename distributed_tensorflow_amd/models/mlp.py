@@ -172,6 +172,7 @@ class MLPEngine:
                     "tW2": torch.empty_like(self.p["W2"]), "tb2": torch.empty_like(self.p["b2"]),
                     "a2b": torch.zeros((self.B, self.H), dtype=torch.float32, device=dev),
                     "zws3": torch.zeros((3 * 2048,), dtype=torch.float32, device=dev),
+                    "w1t": torch.zeros((2, self.H, self.K), dtype=torch.float32, device=dev),
                 }
             q = hb.DtfPipeDesc()
             for k, t in self._pipe_bufs.items():

@@ -71,6 +71,7 @@ class DtfPipeDesc(C.Structure):
         ("gram", C.c_void_p),
         ("gram_ld", C.c_int32),
         ("reserved", C.c_int32),
+        ("w1t", C.c_void_p),
     ]
 
 
@@ -180,6 +181,9 @@ def load(required: bool = False) -> Optional[C.CDLL]:
                     raise OSError(f"{_LIB_PATH} was built from other sources: sizeof({mirror.__name__}) is "
                                   f"{lib.dtf_abi_sizeof(which)} there and {C.sizeof(mirror)} here; rebuild with "
                                   f"python -m distributed_tensorflow_amd.build")
+            if os.environ.get("DTF_PIPE_PARTS") is not None:       # timing experiments (results are then wrong)
+                lib.dtf_debug_set_pipe_parts.argtypes = [C.c_int]
+                lib.dtf_debug_set_pipe_parts(int(os.environ["DTF_PIPE_PARTS"]))
             if os.environ.get("DTF_PIPE_ORDER") is not None:       # tuning experiments (see step_pipe_kernel)
                 lib.dtf_debug_set_pipe_order.argtypes = [C.c_int]
                 lib.dtf_debug_set_pipe_order(int(os.environ["DTF_PIPE_ORDER"]))
