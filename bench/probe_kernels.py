@@ -184,7 +184,7 @@ def pipe_block_stamps():
     g.replay()
     torch.cuda.synchronize()
     s = stamps.cpu().view(-1, 2)
-    na = int(os.environ.get("DTF_PROBE_NA", "3"))
+    na = int(os.environ.get("DTF_PROBE_NA", "5"))
     nd = (784 + 16 * na - 1) // (16 * na) * 7          # dW1 tiles
     nbk = nd + 7 + 1                                    # + dW2 tiles, statistics
     b, f = s[256:256 + nbk], s[768:768 + 169]
@@ -207,8 +207,8 @@ def pipe_block_stamps():
         ends[len(ends) // 2], ends[len(ends) * 9 // 10], ends[len(ends) * 99 // 100], ends[-1]))
 
 
-def pipe_fwd_stamps(block=512 + 30):
-    """Phase stamps of one forward tile of the one-launch step."""
+def pipe_fwd_stamps(block=512 + 30, names=None):
+    """Phase stamps of one forward tile of the one-launch step (block < 512: of a backward tile)."""
     eng = make_engine()
     lib = hb.require()
     nb, B = eng.batches_per_epoch, eng.B
@@ -231,9 +231,12 @@ def pipe_fwd_stamps(block=512 + 30):
     g.replay()
     torch.cuda.synchronize()
     s = stamps.cpu().view(16, 2)
-    names = ["start", "offsets + loads issued", "stage + softmax (2 syncs)", "contraction + dz2 + a2^T dz3 (+sync)",
-             "correction + partials to LDS (+sync)", "reduce + activation + store (+sync)", "logit partials + atomics", "end"]
-    print("one-launch step, forward tile %d (thread 0): wall ns / shader cycles" % (block - 512))
+    if names is None:
+        names = ["start", "offsets + loads issued", "stage + softmax (2 syncs)", "contraction + dz2 + a2^T dz3 (+sync)",
+                 "correction + partials to LDS (+sync)", "reduce + activation + store (+sync)", "logit partials + atomics", "end"]
+        print("one-launch step, forward tile %d (thread 0): wall ns / shader cycles" % (block - 512))
+    else:
+        print("one-launch step, backward tile %d (thread 0): wall ns / shader cycles" % block)
     for i in range(1, 8):
         print("  %-40s %7d ns %8d cyc" % (names[i], (s[i, 0] - s[i - 1, 0]) * 10, s[i, 1] - s[i - 1, 1]))
     print("  %-40s %7d ns" % ("total", (s[7, 0] - s[0, 0]) * 10))
@@ -242,6 +245,11 @@ def pipe_fwd_stamps(block=512 + 30):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pipe":
         pipe_block_stamps()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd":
+        for blk in (8, 40):
+            pipe_fwd_stamps(blk, ["start", "loads issued", "stage+softmax (2 syncs)", "contraction loop",
+                                  "partials to LDS+sync", "reduce+store", "db1", "end"])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fwd":
         for blk in (512 + 30, 512 + 100, 512 + 160):

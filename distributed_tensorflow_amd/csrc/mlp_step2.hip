@@ -1150,12 +1150,13 @@ struct PipeParams {
   int front;               // order 1: backward tiles placed ahead of the forward tiles
 };
 
-// Backward dW1 tiles of the one-launch step are 48 x 16 (NA = 3): 17 x 7 + 7 dW2 tiles + the statistics block = 127
-// workgroups next to the 169 forward tiles.  With the placement of step_pipe_kernel all forward tiles and the statistics
-// block then have a CU of their own and 40 CUs hold two backward tiles.  Measured per step on one box: NA = 2 (183
-// backward workgroups, 10 forward tiles share a CU) 8.24 us, NA = 3 8.10 us, NA = 4 8.12 us.
+// Backward dW1 tiles of the one-launch step are 80 x 16 (NA = 5): 10 x 7 + 7 dW2 tiles + the statistics block = 78
+// workgroups next to the 169 forward tiles, 247 <= 256: every workgroup of the launch has a CU of its own.  (A
+// workgroup that shares its CU runs 1.3 - 2 times longer, and the launch ends with its last workgroup.)  Measured per
+// step on one box with the transposed W1 image: NA = 3 (127 backward workgroups, 40 CUs hold two) 7.88 us, NA = 4
+// 7.87 us, NA = 5 7.45 us, NA = 6 7.48 us.
 #ifndef DTF_PIPE_NA
-#define DTF_PIPE_NA 3
+#define DTF_PIPE_NA 5
 #endif
 constexpr int kPipeNA = DTF_PIPE_NA;
 constexpr int kPipeRed = 72;          // row stride of the cross-wave reduction image: 64 lanes + 8, so that the four
@@ -1371,8 +1372,9 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeParams& pp, float* smem,
   DTF_BLOCK_STAMP_AT(p.bs, lin, 1);
 }
 
-// Placement (order 1).  The launch has more workgroups than the chip has CUs (169 forward + 127 backward tiles on 256
-// CUs); all of them are resident at once and workgroup i + 256 shares its CU with workgroup i, so both run slower.  The
+// Placement (order 1).  When the launch has more workgroups than the chip has CUs (smaller backward tiles: 169 forward +
+// 127 or 183 backward tiles on 256 CUs), all of them are resident at once and workgroup i + 256 shares its CU with
+// workgroup i, so both run slower.  The
 // forward tiles and the statistics block are the long ones (the critical path of the step).  The grid is ordered
 //     [front backward tiles] [all forward tiles] [statistics] [the other backward tiles],  front + forward tiles = 255,
 // so that the statistics block and all but a few forward tiles have a CU of their own, nearly every shared CU holds two
