@@ -1,8 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/r2c
-timeout -k 10 300 python bench.py --gpus 1 > gpurun_out/r2c/bench_1gpu.json 2> gpurun_out/r2c/bench_1gpu.err || exit 1
-cat gpurun_out/r2c/bench_1gpu.json
-timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r2c/bench_1gpu_s20.json 2>/dev/null || exit 1
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2c/trace -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 2200 --warmup 550 > $GRAFT_REPO_ROOT/gpurun_out/r2c/trace.log 2>&1 || exit 1
-cd $GRAFT_REPO_ROOT && find gpurun_out/r2c/trace -name "*kernel_stats.csv" | head -1 | xargs head -12 | cut -c1-180
+mkdir -p gpurun_out/r2d
+timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -6 || exit 1
+DTF_BENCH_SHARE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 > gpurun_out/r2d/rehearsal2.out 2> gpurun_out/r2d/rehearsal2.err || { tail -20 gpurun_out/r2d/rehearsal2.err; exit 1; }
+grep '^{"metric"' gpurun_out/r2d/rehearsal2.out | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('mode_ms_per_step'), d.get('ranks_seen'), d.get('sec_per_epoch'), list(d.get('async_modes',{}).keys()), d.get('ingraph',{}).get('ms_per_step') if isinstance(d.get('ingraph'),dict) else d.get('ingraph'))"

@@ -124,6 +124,9 @@ int dtf_gather_gram(const float* src, const int64_t* perm, float* dst, float* gr
 int dtf_xgmi_max_ranks(void);
 // Kernels on `dev` may dereference memory of `peer` afterwards (DTF_ERR_UNSUPPORTED: no direct path).
 int dtf_enable_peer_access(int dev, int peer);
+// 1 when a kernel on stream_b can run while a kernel on stream_a (same device) waits for it, 0 when the two streams
+// share a hardware queue (the waiting kernel gave up after timeout_us), < 0 on a HIP error.
+int dtf_streams_independent(void* stream_a, void* stream_b, int timeout_us);
 // Zero-filled device memory that other processes may map; uncached != 0 for words that one GPU
 // polls while another writes them.
 int dtf_xgmi_alloc(void** out, int64_t bytes, int uncached);

@@ -234,6 +234,39 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int dtf_xgmi_max_ranks(void) { return kMaxRanks; }
 
+// ---- can a kernel on stream b run while a kernel on stream a waits for it? ---------------------------------------
+// The streams of one process are multiplexed onto a few hardware queues (4 by default), a queue runs its kernels in
+// order, and which queue a stream gets depends on what the process did before.  Two streams whose kernels wait for
+// EACH OTHER (towers sharing a GPU) must therefore be checked, not assumed, to sit on different queues.
+namespace {
+__global__ void wait_flag_kernel(int* flag, int* out, long long timeout_ticks) {
+  const long long t0 = (long long)wall_clock64();
+  int seen = 0;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &&
+         (long long)wall_clock64() - t0 < timeout_ticks)
+    __builtin_amdgcn_s_sleep(8);
+  *out = seen;
+}
+__global__ void set_flag_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+
+// 1: yes, 0: the waiting kernel timed out (the streams share a queue), < 0: a HIP call failed.
+extern "C" int dtf_streams_independent(void* stream_a, void* stream_b, int timeout_us) {
+  hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+  int* buf = nullptr;
+  if (hipMalloc(&buf, 2 * sizeof(int)) != hipSuccess) return -1;
+  int result = -1, seen = 0;
+  if (hipMemsetAsync(buf, 0, 2 * sizeof(int), a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) {
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(1), 0, a, buf, buf + 1, (long long)timeout_us * 100);   // 100 MHz
+    hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, b, buf);
+    if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+        hipMemcpy(&seen, buf + 1, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+      result = seen ? 1 : 0;
+  }
+  (void)hipFree(buf);
+  return result;
+}
+
 // Let kernels launched on device `dev` dereference memory that lives on device `peer` (a shard mapped from a
 // ps task on another GPU).  Already-enabled access is success; the current device is restored.
 extern "C" int dtf_enable_peer_access(int dev, int peer) {

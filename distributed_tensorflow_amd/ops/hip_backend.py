@@ -439,6 +439,21 @@ def enable_peer_access(device: torch.device, peer: torch.device) -> None:
         _check(require().dtf_enable_peer_access(int(a), int(b)), f"peer access cuda:{a} -> cuda:{b}")
 
 
+def streams_independent(a: "torch.cuda.Stream", b: "torch.cuda.Stream", timeout_us: int = 20000) -> bool:
+    """Whether a kernel on ``b`` runs while a kernel on ``a`` waits for it (both directions are checked): False when the
+    two streams of this process share a hardware queue."""
+    lib = require()
+    lib.dtf_streams_independent.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.dtf_streams_independent.restype = C.c_int
+    for x, y in ((a, b), (b, a)):
+        rc = lib.dtf_streams_independent(x.cuda_stream, y.cuda_stream, int(timeout_us))
+        if rc < 0:
+            raise HipKernelError("dtf_streams_independent: HIP error")
+        if rc == 0:
+            return False
+    return True
+
+
 def build_info() -> str:
     lib = load()
     return lib.dtf_hip_build_info().decode() if lib is not None else "unavailable"

@@ -186,9 +186,10 @@ class InGraphEngine:
         self._loop = None
         self.streams = []
         self.towers = []
+        self._spare_streams = []
         for t, dev in enumerate(self.devices):
             with torch.cuda.device(dev):
-                st = torch.cuda.Stream(device=dev)
+                st = self._stream_for_tower(dev)
                 with torch.cuda.stream(st):
                     ds = DeviceDataset(images, labels, dev, batch, seed=data_seed + t)   # a different shuffle per tower
                     tr = XgmiFusedTrainer(device=dev, dataset=ds, batch=batch, lr=lr, seed=seed, rank=t, world=self.n,
@@ -203,6 +204,21 @@ class InGraphEngine:
         self._graph_keys = set()
 
     # -- helpers --------------------------------------------------------------------------------------
+    def _stream_for_tower(self, dev):
+        """A stream whose kernels can run while the kernels of every earlier tower on the same GPU wait for them.
+
+        The streams of a process share a few hardware queues and a queue runs its kernels in order; which queue a new
+        stream lands on depends on what the process did before.  Towers on one GPU wait for each other inside their
+        backward launches, so two of them on one queue would wait until the exchange's time limit."""
+        mates = [s for s, d in zip(self.streams, self.devices) if d == dev]
+        for _ in range(16):
+            st = torch.cuda.Stream(device=dev)
+            if all(hb.streams_independent(m, st) for m in mates):
+                return st
+            self._spare_streams.append(st)           # keep it, so that the pool hands out a different one next
+        raise RuntimeError(f"no stream on {dev} found that runs beside the {len(mates)} tower stream(s) already there: "
+                           "the hardware queues of this process are taken (GPU_MAX_HW_QUEUES)")
+
     def _on(self, t: int):
         import contextlib
 

@@ -332,6 +332,55 @@ def test_device_dataset_refresh_uses_the_fused_kernel_and_matches_the_library_pa
     torch.testing.assert_close(a.gram, b.gram, rtol=1e-5, atol=1e-5)
 
 
+def test_drawing_the_next_order_late_does_not_change_the_orders():
+    """stage_ahead() only moves the host's draw of the next permutation behind queued work: same sequence either way."""
+    from distributed_tensorflow_amd.data import DeviceDataset
+
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.rand(530, 64, generator=g), torch.eye(10)[torch.randint(0, 10, (530,), generator=g)]
+    a, b = DeviceDataset(x, y, DEV, 100, seed=4), DeviceDataset(x, y, DEV, 100, seed=4)
+    for epoch in range(4):
+        a.shuffle_epoch()
+        a.stage_ahead()
+        a.stage_ahead()                       # nothing left to do: no second draw
+        b.shuffle_epoch()                     # draws when the next reshuffle takes it
+        assert torch.equal(a.x_epoch, b.x_epoch) and torch.equal(a.y_epoch, b.y_epoch), epoch
+
+
+def test_window_results_fetched_behind_the_next_window_equal_the_blocking_reads():
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.rand(1230, 784, generator=g), torch.eye(10)[torch.randint(0, 10, (1230,), generator=g)]
+    runs = []
+    for pipelined in (True, False):
+        ds = DeviceDataset(x, y, DEV, 100, seed=1)
+        tr = build_replica_trainer(mode="single", device=DEV, dataset=ds, batch=100, lr=0.01, seed=2, chunk=5)
+        out, pending = [], None
+        for k in (5, 5, 2, 5, 5):            # 12 batches per epoch: the fourth window starts a new epoch
+            first = tr.engine._host_cursor
+            tr.run_steps(k)
+            if pipelined:
+                h = tr.fetch_window_async(first, k, want_history=True)
+                if pending is not None:
+                    out.append(pending.result())
+                pending = h
+            else:
+                losses, accs = tr.engine.history(first, k)
+                out.append((tr.last_loss(), losses, accs, float(tr.global_step_value())))
+        if pending is not None:
+            out.append(pending.result())
+        runs.append(out)
+    for (c0, l0, a0, g0), (c1, l1, a1, g1) in zip(*runs):
+        # (two training runs: the logit partial sums meet through float atomics, whose order varies run to run)
+        assert abs(c0 - c1) < 1e-4 * max(1.0, abs(c1)) and g0 == g1
+        assert float(l0[-1]) == c0 and float(l1[-1]) == c1
+        torch.testing.assert_close(l0, l1, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(a0, a1, rtol=0, atol=0.011)
+    assert [r[3] for r in runs[0]] == [5.0, 10.0, 12.0, 17.0, 22.0]
+
+
 @pytest.mark.parametrize("n,count", [(79516, 1), (79516, 2), (79516, 8), (1003, 3), (5, 16)])
 def test_sum_apply_is_n_mailboxes_in_one_launch(n, count):
     p = _rand(n, seed=20)

@@ -72,3 +72,21 @@ def test_in_graph_towers_mean_gradient_and_identical_replicas():
         torch.testing.assert_close(got[k], p[k] - 0.05 * g[k], rtol=1e-5, atol=1e-6)
     tw.run_steps(5)                       # crosses the 4-batch epoch boundary (reshuffle)
     assert tw.replicas_identical() and tw.global_step_value() == 6
+
+
+def test_window_fetch_on_the_cpu_path_returns_the_same_values_as_the_blocking_calls():
+    import numpy as np
+    import torch
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(330, 784, generator=g), torch.eye(10)[torch.randint(0, 10, (330,), generator=g)]
+    ds = DeviceDataset(x, y, "cpu", 100, seed=1)
+    tr = build_replica_trainer(mode="single", device=torch.device("cpu"), dataset=ds, batch=100, lr=0.01, seed=2, chunk=2)
+    first = tr.engine._host_cursor
+    tr.run_steps(3)
+    cost, losses, accs, gstep = tr.fetch_window_async(first, 3, want_history=True).result()
+    want_l, want_a = tr.engine.history(first, 3)
+    assert cost == tr.last_loss() and gstep == 3.0
+    assert np.array_equal(losses.numpy(), want_l.numpy()) and np.array_equal(accs.numpy(), want_a.numpy())

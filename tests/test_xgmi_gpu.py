@@ -187,6 +187,18 @@ def test_pushing_backward_matches_the_fp32_oracle():
 
 
 @pytest.mark.gpu
+def test_stream_probe_tells_streams_on_one_hardware_queue_from_streams_that_run_side_by_side():
+    import torch
+
+    from distributed_tensorflow_amd.ops import hip_backend as hb
+
+    a = torch.cuda.Stream()
+    assert hb.streams_independent(a, a, timeout_us=2000) is False      # a kernel cannot overtake its own stream
+    others = [torch.cuda.Stream() for _ in range(8)]
+    assert any(hb.streams_independent(a, b, timeout_us=5000) for b in others)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(200)
 @pytest.mark.parametrize("towers,compact", [(2, False), (2, True)])
 def test_in_graph_engine_towers_on_one_gpu_match_the_mean_gradient_oracle(towers, compact):
@@ -210,7 +222,9 @@ def test_in_graph_engine_towers_on_one_gpu_match_the_mean_gradient_oracle(towers
         sets = [(tr.ds.x_epoch.cpu().clone(), tr.ds.y_epoch.cpu().clone()) for tr in eng.towers]
         eng.prepare((5,))
         eng.run_steps(5)                       # chunks of 4 + 1, inside the first 6-batch epoch
-        assert eng.healthy() and eng.replicas_identical() and eng.global_step_value() == 5
+        assert eng.healthy(), "an exchange between the towers timed out"
+        assert eng.global_step_value() == 5
+        assert eng.replicas_identical()
         assert eng.host_calls_per_chunk() == 1
         for step in range(5):
             g = {k: torch.zeros_like(v) for k, v in p.items()}
