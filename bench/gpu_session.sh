@@ -1,5 +1,8 @@
 set -o pipefail
-mkdir -p gpurun_out/r2d
-timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -6 || exit 1
-DTF_BENCH_SHARE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 > gpurun_out/r2d/rehearsal2.out 2> gpurun_out/r2d/rehearsal2.err || { tail -20 gpurun_out/r2d/rehearsal2.err; exit 1; }
-grep '^{"metric"' gpurun_out/r2d/rehearsal2.out | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('mode_ms_per_step'), d.get('ranks_seen'), d.get('sec_per_epoch'), list(d.get('async_modes',{}).keys()), d.get('ingraph',{}).get('ms_per_step') if isinstance(d.get('ingraph'),dict) else d.get('ingraph'))"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+export DTF_BENCH_ASYNC=0
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d $R/gpurun_out/pmcf1 -- python3 $R/bench.py --gpus 1 --steps 1100 --warmup 550 > $R/gpurun_out/pmcf1.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmcf2 -- python3 $R/bench.py --gpus 1 --steps 1100 --warmup 550 > $R/gpurun_out/pmcf2.log 2>&1 || exit 1
+timeout -s KILL 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $R/gpurun_out/pmcf3 -- python3 $R/bench.py --gpus 1 --steps 1100 --warmup 550 > $R/gpurun_out/pmcf3.log 2>&1 || exit 1
+cd $R && python bench/summarize_pmc.py gpurun_out/pmcf1 gpurun_out/pmcf2 gpurun_out/pmcf3
