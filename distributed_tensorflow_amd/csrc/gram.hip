@@ -151,7 +151,8 @@ __global__ __launch_bounds__(kThreads, 3) void gather_gram_kernel(GramArgs a) {
     }
     __syncthreads();
     // the epoch-ordered copy: stored from the staging registers AFTER the barrier, so that no wave waits at the
-    // barrier for another wave's global stores (the registers are reloaded right below)
+    // barrier for another wave's global stores (the registers are reloaded right below); streaming stores: 172 MB
+    // that nobody reads before the kernel ends (loads + stores alone 134 -> 97 us)
     if (a.dst != nullptr && (a.parts & 4) && kq_ok) {
 #pragma unroll
       for (int u = 0; u < kLoads; ++u) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 3) void gather_gram_kernel(GramArgs a) {
         const int rgl = isA ? rg : rg - kRowsA / 8;
         const bool ok = (isA ? m_base + 8 * rgl + r8 : 8 * rgl + r8) < B;
         if (ok && (isA || store_b))
-          *reinterpret_cast<f32x4*>(dst + (isA ? dstA : dstB) + (unsigned)(8 * rgl) * rowbytes + (unsigned)kq * 16u) = stage[u];
+          __builtin_nontemporal_store(stage[u], reinterpret_cast<f32x4*>(dst + (isA ? dstA : dstB) + (unsigned)(8 * rgl) * rowbytes + (unsigned)kq * 16u));
       }
     }
     if (c + 1 < nchunks && (a.parts & 1)) DTF_GRAM_ISSUE(c + 1);       // lands while this chunk is multiplied
