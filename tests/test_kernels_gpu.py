@@ -180,18 +180,19 @@ def test_eval_matches_reference():
     assert abs(acc - float(wa)) < 1e-4
 
 
-@pytest.mark.parametrize("M,K,H,act", [(10000, 784, 100, 0), (77, 784, 100, 1), (48, 64, 112, 0), (1000, 260, 37, 0)])
-def test_one_kernel_evaluation_matches_reference_and_two_kernel_path(M, K, H, act):
+@pytest.mark.parametrize("M,K,H,act,ncls", [(10000, 784, 100, 0, 10), (77, 784, 100, 1, 10), (48, 64, 112, 0, 16),
+                                              (1000, 260, 37, 0, 3), (1, 4, 1, 0, 2), (49, 1024, 5, 1, 10)])
+def test_one_kernel_evaluation_matches_reference_and_two_kernel_path(M, K, H, act, ncls):
     """eval.hip against the fp64 oracle and against the first-layer GEMM + head kernel pair it replaces."""
     import ctypes as C
     lib = hb.require()
     g = torch.Generator().manual_seed(M + K)
     x = torch.rand(M, K, generator=g).to(DEV)
-    y = torch.nn.functional.one_hot(torch.randint(0, 10, (M,), generator=g), 10).float().to(DEV)
+    y = torch.nn.functional.one_hot(torch.randint(0, ncls, (M,), generator=g), ncls).float().to(DEV)
     W1 = (torch.randn(K, H, generator=g) * 0.1).to(DEV)
     b1 = torch.randn(H, generator=g).to(DEV)
-    W2 = torch.randn(H, 10, generator=g).to(DEV)
-    b2 = torch.randn(10, generator=g).to(DEV)
+    W2 = torch.randn(H, ncls, generator=g).to(DEV)
+    b2 = torch.randn(ncls, generator=g).to(DEV)
     ws = torch.empty(M * H, device=DEV)
     out = {}
     lib.dtf_debug_set_eval_fused.argtypes = [C.c_int]
