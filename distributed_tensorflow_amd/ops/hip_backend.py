@@ -216,7 +216,15 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """Handle of the current stream of the current device.  (``torch.cuda.current_stream()`` resolves its device
+    through ``torch.cuda.is_available()``, a driver call of ~12 us: too much for a call made before every launch.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
