@@ -1,5 +1,12 @@
+# One GPU session: the GPU test suite, the headline benchmark, a kernel trace of it.  Every GPU step has its own time
+# limit and the script stops at the first failure.  Usage: gpurun --timeout 1200 -- 'bash bench/gpu_session.sh'
 set -o pipefail
-timeout -k 10 200 python tfsingle.py --epochs 8 --logs_path /tmp/lg1 2>&1 | grep "Total Time" | tail -4 | tr '\n' ' '; echo
-timeout -k 10 200 python tfsingle.py --epochs 8 --nosummaries 2>&1 | grep "Total Time" | tail -4 | tr '\n' ' '; echo
-timeout -k 10 300 python bench/run_cluster.py --script tfdist_between.py --ps 1 --workers 1 --transport ipc --epochs 8 2>&1 | tail -1 | cut -c1-400
-timeout -k 10 300 python bench/run_cluster.py --script tfdist_between_sync.py --ps 1 --workers 2 --transport ipc --epochs 8 2>&1 | tail -1 | cut -c1-500
+out=gpurun_out/session
+mkdir -p $out
+timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | tail -4 || exit 1
+timeout -k 10 300 python bench.py --gpus 1 > $out/bench_1gpu.json 2> $out/bench_1gpu.err || exit 1
+python -c "import json; d=json.load(open('$out/bench_1gpu.json')); print(d['value'], d['ms_per_step'], d['sec_per_epoch'], d['vs_baseline'])"
+root=$PWD
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -- python3 $root/bench.py --gpus 1 --steps 2200 --warmup 550 > $root/$out/trace.log 2>&1 || exit 1
+cd $root && find $out/trace -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-160
