@@ -1650,9 +1650,16 @@ extern "C" void dtf_debug_set_bwd_stamp_block(int block) { g_stamp_block = block
 // {start, end} wall-clock stamps of the next two-launch steps; null disables.
 extern "C" void dtf_debug_set_block_stamps(long long* device_buffer) { g_block_stamps = device_buffer; }
 
-// dst[c][r] = src[r][c] for a [rows][cols] matrix (32 x 32 tiles through LDS; block (32, 8)).
-__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+// Prologue of a one-launch chunk in ONE launch: dst[c][r] = src[r][c] for a [rows][cols] matrix (32 x 32 tiles through
+// LDS; block (32, 8), grid.x = row tiles + 1), and the workgroups of the extra grid column clear `zero_n` floats at `zero`.
+__global__ void transpose_and_zero_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                          float* __restrict__ zero, int zero_n) {
   __shared__ float tile[32][33];
+  if (blockIdx.x == gridDim.x - 1) {
+    const int t = threadIdx.y * 32 + threadIdx.x;
+    for (int i = blockIdx.y * 256 + t; i < zero_n; i += gridDim.y * 256) zero[i] = 0.f;
+    return;
+  }
   const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   for (int i = threadIdx.y; i < 32; i += 8)
     if (r0 + i < rows && c0 + threadIdx.x < cols) tile[i][threadIdx.x] = src[(long)(r0 + i) * cols + c0 + threadIdx.x];
@@ -1700,7 +1707,8 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
   float* zw[3] = {q->zws3, q->zws3 + 2048, q->zws3 + 4096};
   // (a kernel, not hipMemsetAsync: inside a stream capture the memset was observed to take effect at
   // capture time only — later replays of the graph then started from a dirty accumulator)
-  hipLaunchKernelGGL(zero_floats_kernel, dim3(6), dim3(1024), 0, stream, q->zws3, 3 * 2048);
+  // (n > 1: the accumulators are cleared by the transposition launch below, which precedes every kernel that uses them)
+  if (n == 1) hipLaunchKernelGGL(zero_floats_kernel, dim3(6), dim3(1024), 0, stream, q->zws3, 3 * 2048);
   // The last step has to leave the parameters in the caller's tensors, so an odd chunk starts
   // from the twin set (a copy of the same values).
   const bool start_twin = (n & 1) != 0;
@@ -1710,6 +1718,13 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
         hipMemcpyAsync(twin.W2, canon.W2, sizeof(float) * H * C, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
         hipMemcpyAsync(twin.b2, canon.b2, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return DTF_ERR_LAUNCH;
+  }
+  if (n > 1) {
+    // the transposed image the first one-launch forward reads (every later one is stored by a backward); the values are
+    // the caller's whichever set the chunk starts from
+    float* w1t_first = start_twin ? q->w1t + (size_t)K * H : q->w1t;
+    hipLaunchKernelGGL(transpose_and_zero_kernel, dim3((K + 31) / 32 + 1, (H + 31) / 32), dim3(32, 8), 0, stream, d->W1,
+                       w1t_first, K, H, q->zws3, 3 * 2048);
   }
   // forward of the first step, from the caller's parameters
   {
@@ -1725,9 +1740,6 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
 #undef DTF_F0_ARGS
   }
   Set cur = start_twin ? twin : canon;
-  if (n > 1) {          // the transposed image the first one-launch forward reads; every later one is stored by a backward
-    hipLaunchKernelGGL(transpose_kernel, dim3((K + 31) / 32, (H + 31) / 32), dim3(32, 8), 0, stream, d->W1, cur.W1T, K, H);
-  }
   for (int i = 0; i < n; ++i) {
     const Set nxt = (cur.W1 == canon.W1) ? twin : canon;
     const long bi = first_batch + i;
