@@ -46,7 +46,7 @@ for fused in (1, 0):
 lib.dtf_debug_set_eval_fused(1)
 if len(sys.argv) > 1 and sys.argv[1] == "parts":
     lib.dtf_debug_set_eval_parts.argtypes = [C.c_int]
-    for parts, what in ((1, "loads + LDS writes only"), (2, "products only"), (0, "neither"), (3, "all"), (7, "all but the x loads"), (11, "all but the W1 loads")):
+    for parts, what in ((1, "loads + LDS writes only"), (2, "products only"), (0, "neither"), (3, "all")):
         lib.dtf_debug_set_eval_parts(parts)
         for _ in range(3):
             hb.mlp_eval(x, y, W1, b1, W2, b2, 0, ws, ls, cc)
