@@ -72,6 +72,10 @@ int dtf_mlp_step_grad(const DtfMlpDesc* d, int batch_index, int parity, float gr
 // batches).  Same results as n calls of dtf_mlp_step_fused up to fp32 rounding.
 int dtf_mlp_chunk_pipelined_supported(int B, int K, int H, int C);
 int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n, void* stream);
+// The same with chunks that chain: see the flags at the definition.
+#define DTF_PIPE_CARRY_IN 1
+#define DTF_PIPE_CARRY_OUT 2
+int dtf_mlp_chunk_pipelined_ex(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n, int flags, void* stream);
 // cursor += n  (one thread).
 int dtf_advance_cursor(int32_t* cursor, int n, void* stream);
 

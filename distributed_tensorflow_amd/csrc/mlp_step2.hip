@@ -349,7 +349,7 @@ struct BwdParams {
   // One-launch step: between the first and the last step of a chunk W1 lives TRANSPOSED ([H][K]) only -- the form the
   // forward tiles read (a tile's 8 columns are 8 contiguous rows, a lane's four k one 16-byte load).
   const float* rW1T;      // old values, transposed (null: read rW1)
-  float* oW1T;            // where the new values go, transposed (null: store oW1)
+  float* oW1T;            // where the new values go, transposed (null: not wanted); then oW1 may be null instead
   float* ob1;             // fused: b1 to WRITE; grad: gb1
   const float* rW1;       // fused: W1 holding the OLD values (== oW1 for an in-place update); grad: gW1
   const float* rb1;       // same for b1
@@ -984,10 +984,8 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
           const int orow = k0 + o_trow, ocol = h0 + o_tcol;
           if (orow < K && ocol < H) {
             const float v = p.fused ? wold[u] - lr * s : gs * s;
-            if (p.oW1T != nullptr)
-              p.oW1T[(long)ocol * K + orow] = v;
-            else
-              p.oW1[(long)orow * H + ocol] = v;
+            if (p.oW1T != nullptr) p.oW1T[(long)ocol * K + orow] = v;
+            if (p.oW1 != nullptr) p.oW1[(long)orow * H + ocol] = v;
           }
         } else if (o_sub == 0) {
           const int h = h0 + o_trow;
@@ -1687,8 +1685,15 @@ extern "C" int dtf_mlp_chunk_pipelined_supported(int B, int K, int H, int C) {
   return dtf_step2_supported(B, K, H, C) && (K & 3) == 0 && K >= 16 && K <= 1024 ? 1 : 0;
 }
 
-extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n,
-                                       void* stream_) {
+// flags: DTF_PIPE_CARRY_IN -- the previous chunk ended at `first_batch` with DTF_PIPE_CARRY_OUT and nothing has touched
+// the parameters, the resident set or the chunk state since: the forward of batch first_batch and the transposed image
+// of the current W1 are where this chunk expects them, so it consists of its n step launches and nothing else;
+// DTF_PIPE_CARRY_OUT -- the last launch also runs the forward of batch first_batch + n (which must exist in this epoch)
+// and stores W1 in both layouts.  Everything a chunk leaves behind is placed by the POSITION of the batch in the epoch
+// (activations of batch b in buffer b & 1, its logits in accumulator b % 3, the transposed W1 before step b in image
+// b & 1), so chunks captured into graphs chain in whatever sizes they were captured.
+extern "C" int dtf_mlp_chunk_pipelined_ex(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n, int flags,
+                                          void* stream_) {
   if (!d || !q) return DTF_ERR_NULL;
   hipStream_t stream = (hipStream_t)stream_;
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
@@ -1697,40 +1702,46 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
   if (!q->tW1 || !q->tb1 || !q->tW2 || !q->tb2 || !q->a2b || !q->zws3 || !q->gram || !q->w1t) return DTF_ERR_NULL;
   if (n < 1 || first_batch < 0 || first_batch + n > d->batches_per_epoch) return DTF_ERR_SHAPE;
   if (q->gram_ld < B || (q->gram_ld & 15) || q->gram_ld > 128) return DTF_ERR_SHAPE;
+  const bool carry_in = (flags & DTF_PIPE_CARRY_IN) != 0, carry_out = (flags & DTF_PIPE_CARRY_OUT) != 0;
+  if (carry_out && first_batch + n >= d->batches_per_epoch) return DTF_ERR_SHAPE;
   const int R = ((B + 15) / 16) * 16;
   const int tiles_m8 = (B + 7) / 8, tiles_n8 = (H + 7) / 8, tiles_h16 = (H + 15) / 16;
   const int tiles_k = (K + 16 * kPipeNA - 1) / (16 * kPipeNA);
   const int cq = (C + 3) / 4;
-  struct Set { float *W1, *b1, *W2, *b2, *W1T; };
-  const Set canon{d->W1, d->b1, d->W2, d->b2, q->w1t}, twin{q->tW1, q->tb1, q->tW2, q->tb2, q->w1t + (size_t)K * H};
+  // W1 lives transposed inside the chunk whenever some launch of it has a forward part or reads a carried image
+  const bool use_t = n > 1 || carry_in || carry_out;
+  struct Set { float *W1, *b1, *W2, *b2; };
+  const Set canon{d->W1, d->b1, d->W2, d->b2}, twin{q->tW1, q->tb1, q->tW2, q->tb2};
+  float* w1t[2] = {q->w1t, q->w1t + (size_t)K * H};
   float* a2buf[2] = {d->z2, q->a2b};
   float* zw[3] = {q->zws3, q->zws3 + 2048, q->zws3 + 4096};
-  // (a kernel, not hipMemsetAsync: inside a stream capture the memset was observed to take effect at
-  // capture time only — later replays of the graph then started from a dirty accumulator)
-  // (n > 1: the accumulators are cleared by the transposition launch below, which precedes every kernel that uses them)
-  if (n == 1) hipLaunchKernelGGL(zero_floats_kernel, dim3(6), dim3(1024), 0, stream, q->zws3, 3 * 2048);
+  const long fb = first_batch;
+  if (!carry_in) {
+    // (kernels, not hipMemsetAsync: inside a stream capture the memset was observed to take effect at capture time
+    // only -- later replays of the graph then started from a dirty accumulator)
+    if (use_t) {
+      // the transposed image the first step reads (every later one is stored by a backward) + clean accumulators
+      hipLaunchKernelGGL(transpose_and_zero_kernel, dim3((K + 31) / 32 + 1, (H + 31) / 32), dim3(32, 8), 0, stream, d->W1,
+                         w1t[fb & 1], K, H, q->zws3, 3 * 2048);
+    } else {
+      hipLaunchKernelGGL(zero_floats_kernel, dim3(6), dim3(1024), 0, stream, q->zws3, 3 * 2048);
+    }
+  }
   // The last step has to leave the parameters in the caller's tensors, so an odd chunk starts
-  // from the twin set (a copy of the same values).
+  // from the twin set (a copy of the same values; W1 only where the chunk reads the plain layout).
   const bool start_twin = (n & 1) != 0;
   if (start_twin) {
-    if (hipMemcpyAsync(twin.W1, canon.W1, sizeof(float) * K * H, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+    if ((!use_t &&
+         hipMemcpyAsync(twin.W1, canon.W1, sizeof(float) * K * H, hipMemcpyDeviceToDevice, stream) != hipSuccess) ||
         hipMemcpyAsync(twin.b1, canon.b1, sizeof(float) * H, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
         hipMemcpyAsync(twin.W2, canon.W2, sizeof(float) * H * C, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
         hipMemcpyAsync(twin.b2, canon.b2, sizeof(float) * C, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return DTF_ERR_LAUNCH;
   }
-  if (n > 1) {
-    // the transposed image the first one-launch forward reads (every later one is stored by a backward); the values are
-    // the caller's whichever set the chunk starts from
-    float* w1t_first = start_twin ? q->w1t + (size_t)K * H : q->w1t;
-    hipLaunchKernelGGL(transpose_and_zero_kernel, dim3((K + 31) / 32 + 1, (H + 31) / 32), dim3(32, 8), 0, stream, d->W1,
-                       w1t_first, K, H, q->zws3, 3 * 2048);
-  }
-  // forward of the first step, from the caller's parameters
-  {
+  if (!carry_in) {        // forward of the first step, from the caller's parameters
     const int ns8 = ((K + 15) / 16 + 31) / 32;
     const dim3 grid(tiles_n8, tiles_m8 + 1), block(kFwdWaves * 64);
-#define DTF_F0_ARGS grid, block, 0, stream, d->x, (long)first_batch, d->W1, d->b1, d->W2, a2buf[0], zw[0], zw[1], \
+#define DTF_F0_ARGS grid, block, 0, stream, d->x, fb, d->W1, d->b1, d->W2, a2buf[fb & 1], zw[fb % 3], zw[(fb + 1) % 3], \
                     R * 16, B, K, H, C, d->act, (float*)nullptr, d->b2, BlockStamps{nullptr}, (unsigned*)nullptr
     if (ns8 == 1) {
       hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_F0_ARGS);
@@ -1742,20 +1753,23 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
   Set cur = start_twin ? twin : canon;
   for (int i = 0; i < n; ++i) {
     const Set nxt = (cur.W1 == canon.W1) ? twin : canon;
-    const long bi = first_batch + i;
+    const long bi = fb + i;
+    const bool last = i == n - 1;
+    const bool fwd_part = !last || carry_out;        // this launch also holds the forward of batch bi + 1
     PipeParams pp;
     BwdParams& p = pp.b;
-    p.a2 = a2buf[i & 1];
-    p.zacc = zw[i % 3];
+    p.a2 = a2buf[bi & 1];
+    p.zacc = zw[bi % 3];
     p.xbase = d->x;
     p.ybase = d->y;
     p.batch_index = bi;
     p.W2r = cur.W2; p.b2r = cur.b2;
     p.rW1 = cur.W1; p.rb1 = cur.b1;
-    p.oW1 = nxt.W1; p.ob1 = nxt.b1; p.oW2 = nxt.W2; p.ob2 = nxt.b2;
-    p.rW1T = n > 1 ? cur.W1T : nullptr;
-    p.oW1T = i + 1 < n ? nxt.W1T : nullptr;       // the last step leaves W1 in the caller's tensor
-    p.zclear = zw[(i + 2) % 3];
+    p.ob1 = nxt.b1; p.oW2 = nxt.W2; p.ob2 = nxt.b2;
+    p.rW1T = use_t ? w1t[bi & 1] : nullptr;
+    p.oW1T = (use_t && fwd_part) ? w1t[(bi + 1) & 1] : nullptr;     // read by the next step, here or in the next chunk
+    p.oW1 = (last || !use_t) ? nxt.W1 : nullptr;                    // the last step leaves W1 in the caller's tensor
+    p.zclear = zw[(bi + 2) % 3];
     p.zclear_n = R * 16;
     p.lr = d->lr;
     p.grad_scale = 1.0f;
@@ -1769,13 +1783,13 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     p.stamps = observed ? g_stamps2 : nullptr;
     p.stamp_block = g_stamp_block >= 0 ? g_stamp_block : tiles_k * tiles_h16 + tiles_h16 + 1 + g_stamp_block;
     p.bs = BlockStamps{g_block_stamps && observed ? g_block_stamps + 2 * 256 : nullptr};
-    pp.W1Tr = cur.W1T; pp.b1r = cur.b1;
+    pp.W1Tr = w1t[bi & 1]; pp.b1r = cur.b1;
     pp.next_index = bi + 1;
     pp.gram = q->gram + (size_t)bi * B * q->gram_ld;
     pp.gram_ld = q->gram_ld;
-    pp.a2_next = a2buf[(i + 1) & 1];
-    pp.zacc_next = zw[(i + 1) % 3];
-    pp.fwd_rows = (i < n - 1) ? tiles_m8 : 0;
+    pp.a2_next = a2buf[(bi + 1) & 1];
+    pp.zacc_next = zw[(bi + 1) % 3];
+    pp.fwd_rows = fwd_part ? tiles_m8 : 0;
     pp.tiles_n8 = tiles_n8;
     pp.tiles_h16 = tiles_h16;
     pp.order = g_pipe_order;
@@ -1799,4 +1813,9 @@ extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q
     cur = nxt;
   }
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_mlp_chunk_pipelined(const DtfMlpDesc* d, const DtfPipeDesc* q, int first_batch, int n,
+                                       void* stream_) {
+  return dtf_mlp_chunk_pipelined_ex(d, q, first_batch, n, 0, stream_);
 }

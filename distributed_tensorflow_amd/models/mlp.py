@@ -115,6 +115,9 @@ class MLPEngine:
         self._gram = None
         self._pipe = None
         self._pipe_bufs = None
+        # one-launch chunks that chain: the batch (position in the epoch) whose forward pass the last chunk left behind
+        # together with the transposed image of the current W1, or None (see chunk_pipelined)
+        self._carry_pos = None
         self._grad_slots = None
         self._slot_descs = {}
 
@@ -138,12 +141,14 @@ class MLPEngine:
         if rebuilt:
             self._desc = None
             self._graphs.clear()
+            self._carry_pos = None
 
     def bind_gram(self, gram: Optional[torch.Tensor]):
         """Attach the Gram blocks of consecutive mini-batches of the bound (epoch-ordered) set:
         ``gram[j, m, i] = 1 + x_{j+1}[m] . x_j[i]`` ([batches_per_epoch - 1, B, ld], zero for i >= B; see
         :meth:`DeviceDataset.enable_pair_gram`).  With them, fused steps run with ONE launch per step
         (``chunk_pipelined``).  The tensor is read in place: refresh its CONTENTS when the set is reshuffled."""
+        self._carry_pos = None
         if gram is None:
             self._gram = self._pipe = None
             return
@@ -182,13 +187,38 @@ class MLPEngine:
             self._pipe = q
         return self._pipe
 
-    def chunk_pipelined(self, pos: int, n: int):
-        """Enqueue n fused steps on batches pos .. pos+n-1 of the epoch, one launch per step (no cursor change)."""
+    def chunk_pipelined(self, pos: int, n: int, carry_in: bool = False, carry_out: bool = False):
+        """Enqueue n fused steps on batches pos .. pos+n-1 of the epoch, one launch per step (no cursor change).
+
+        Chunks chain: with ``carry_out`` the last launch also runs the forward pass of batch pos+n and keeps W1 in
+        both layouts, and the next chunk, started at pos+n with ``carry_in``, consists of its n step launches only (no
+        transposition, no stand-alone forward).  ``carry_in`` is the CALLER's promise that nothing touched the
+        parameters, the bound set or this engine in between (``carried_to`` says where the last chunk left off; every
+        other step method, a rebind and ``invalidate_carry()`` reset it).  When a chunk is captured into a graph the
+        bookkeeping is the replaying caller's (``note_carry``)."""
         if self._gram is None:
             raise RuntimeError("bind_gram() first")
         if pos < 0 or pos + n > self.batches_per_epoch:
             raise ValueError("a pipelined chunk must stay inside one epoch")
-        hb.mlp_chunk_pipelined(self._descriptor(), self._pipe_descriptor(), pos, n)
+        if carry_out and pos + n >= self.batches_per_epoch:
+            raise ValueError("no batch after the chunk in this epoch to run the forward pass of")
+        flags = (hb.PIPE_CARRY_IN if carry_in else 0) | (hb.PIPE_CARRY_OUT if carry_out else 0)
+        hb.mlp_chunk_pipelined(self._descriptor(), self._pipe_descriptor(), pos, n, flags)
+        if not torch.cuda.is_current_stream_capturing():
+            self._carry_pos = pos + n if carry_out else None
+
+    @property
+    def carried_to(self) -> Optional[int]:
+        """Position in the epoch at which a chunk started with ``carry_in`` would be valid, or None."""
+        return self._carry_pos
+
+    def note_carry(self, pos: Optional[int]):
+        """Record what a replayed graph of ``chunk_pipelined(..., carry_out=...)`` left behind."""
+        self._carry_pos = pos
+
+    def invalidate_carry(self):
+        """Call after writing the parameters or the bound set behind the engine's back."""
+        self._carry_pos = None
 
     def set_cursor(self, value: int):
         self._host_cursor = int(value)
@@ -255,6 +285,7 @@ class MLPEngine:
 
     def step_fused(self, batch_index: Optional[int] = None):
         """One SGD step on mini-batch ``batch_index`` of the epoch (default: the cursor's)."""
+        self._carry_pos = None
         bi = self._bi(batch_index)
         if self.on_gpu:
             hb.mlp_step_fused(self._descriptor(), bi, self.parity)
@@ -286,6 +317,7 @@ class MLPEngine:
     def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0, slot: Optional[int] = None):
         """Gradients of mini-batch ``batch_index`` into the gradient tensors (or into gradient slot ``slot``,
         see :meth:`bind_grad_slots`); no update."""
+        self._carry_pos = None
         if self.g is None and slot is None:
             raise RuntimeError("engine was built without gradient tensors")
         bi = self._bi(batch_index)
@@ -305,6 +337,7 @@ class MLPEngine:
     def step_xg(self, batch_index: Optional[int], scale: float, xg: "hb.DtfXgDesc"):
         """Fused step of a synchronous replica: the backward's workgroups exchange their partial gradients
         (scaled by ``scale`` = 1/N) with the peers described by ``xg`` and apply the rank-ordered sum in place."""
+        self._carry_pos = None
         if not self.on_gpu:
             raise RuntimeError("the cross-replica step is a GPU path")
         hb.mlp_step_xg(self._descriptor(), self._bi(batch_index), self.parity, scale, xg)
@@ -314,6 +347,7 @@ class MLPEngine:
         """Step of an asynchronous worker: forward, then a backward whose threads apply ``-lr * g`` of their own
         gradient element directly to the parameter shard that owns it (``PeerShards.step_descriptor``).  The
         engine's own parameters are only read; the caller refreshes them with a pull."""
+        self._carry_pos = None
         if not self.on_gpu:
             raise RuntimeError("the shard-pushing step is a GPU path")
         hb.mlp_step_async(self._descriptor(), self._bi(batch_index), self.parity, shards)
@@ -341,6 +375,7 @@ class MLPEngine:
                     g = self._capture_pipe(pos, n)
                     self._graphs[key] = g
                 g.replay()
+                self._carry_pos = None
             self._host_cursor += n
             return
         if not self.on_gpu or not use_graph:
@@ -385,7 +420,7 @@ class MLPEngine:
                 hb.mlp_step_fused(self._desc, (pos + i) % self.batches_per_epoch, parity0 ^ (i & 1))
         return graph
 
-    def _capture_pipe(self, pos: int, n: int) -> "torch.cuda.CUDAGraph":
+    def _capture_pipe(self, pos: int, n: int, carry_in: bool = False, carry_out: bool = False) -> "torch.cuda.CUDAGraph":
         self._descriptor()
         # Warm up (module load) on a side stream with the training state rolled back afterwards.
         saved = {k: v.clone() for k, v in self.p.items()}
@@ -403,14 +438,16 @@ class MLPEngine:
             self.global_step.copy_(saved_gs)
         self.loss_hist.copy_(saved_hist[0])
         self.acc_hist.copy_(saved_hist[1])
+        self._carry_pos = None          # the warm-up steps overwrote whatever a previous chunk had left behind
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self.chunk_pipelined(pos, n)
+            self.chunk_pipelined(pos, n, carry_in, carry_out)
         return graph
 
     def reset_step_workspace(self, parity: int = 0):
         """Re-establish the ping-pong invariant (after warm-up steps whose effects are rolled back)."""
+        self._carry_pos = None
         self.zws.zero_()
         self.parity = int(parity) & 1
 

@@ -98,6 +98,7 @@ class DtfXgDesc(C.Structure):
 def _declare(lib: C.CDLL) -> None:
     vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
     lib.dtf_mlp_chunk_pipelined.argtypes = [C.POINTER(DtfMlpDesc), C.POINTER(DtfPipeDesc), i32, i32, vp]
+    lib.dtf_mlp_chunk_pipelined_ex.argtypes = [C.POINTER(DtfMlpDesc), C.POINTER(DtfPipeDesc), i32, i32, i32, vp]
     lib.dtf_mlp_chunk_pipelined_supported.argtypes = [i32, i32, i32, i32]
     lib.dtf_mlp_step_fused.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, vp]
     lib.dtf_mlp_step_grad.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, vp]
@@ -407,10 +408,15 @@ def mlp_step_fused(desc: DtfMlpDesc, batch_index: int, parity: int):
            "dtf_mlp_step_fused")
 
 
-def mlp_chunk_pipelined(desc: DtfMlpDesc, pipe: DtfPipeDesc, first_batch: int, n: int):
-    """n fused steps with one launch per step (csrc/mlp_step2.hip: step_pipe_kernel)."""
-    _check(require().dtf_mlp_chunk_pipelined(C.byref(desc), C.byref(pipe), int(first_batch), int(n), _stream()),
-           "dtf_mlp_chunk_pipelined")
+PIPE_CARRY_IN, PIPE_CARRY_OUT = 1, 2
+
+
+def mlp_chunk_pipelined(desc: DtfMlpDesc, pipe: DtfPipeDesc, first_batch: int, n: int, flags: int = 0):
+    """n fused steps with one launch per step (csrc/mlp_step2.hip: step_pipe_kernel).  ``flags``: PIPE_CARRY_IN (the
+    previous chunk ended here with PIPE_CARRY_OUT: no prologue, no stand-alone forward) | PIPE_CARRY_OUT (the last
+    launch also holds the forward of the batch after the chunk)."""
+    _check(require().dtf_mlp_chunk_pipelined_ex(C.byref(desc), C.byref(pipe), int(first_batch), int(n), int(flags),
+                                                _stream()), "dtf_mlp_chunk_pipelined")
 
 
 def mlp_chunk_pipelined_supported(B: int, K: int, H: int, Cn: int) -> bool:

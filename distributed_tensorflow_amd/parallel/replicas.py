@@ -32,6 +32,7 @@ one fused slab per collective, never one call per variable.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -250,6 +251,73 @@ class SingleTrainer(_BaseTrainer):
         if not self.pipelined:
             return super()._capture(pos, n, parity)
         return self.engine._capture_pipe(pos, n)     # chunk-local state only: the parity plays no role
+
+    # -- one-launch chunks that chain -----------------------------------------------------------------------
+    # A chunk whose successor is known to follow in the same epoch ends with the forward pass of the successor's first
+    # batch (and W1 in both layouts), and a chunk that starts where such a chunk ended is nothing but its step launches:
+    # no transposition launch, no stand-alone forward (12 us per chunk, which is what a 20-step run_steps() or the six
+    # windows of an epoch would otherwise pay each time).  What is carried is tracked by the engine and dropped by
+    # anything else that touches it; a graph is captured per (position, length, carry-in, carry-out).
+    def _chains(self) -> bool:
+        return self.pipelined and self.use_graph and os.environ.get("DTF_PIPE_CARRY", "1") != "0"
+
+    def _pipe_graph(self, pos: int, n: int, cin: bool, cout: bool, dset: int, capture: bool = True):
+        key = (pos, n, ("carry", cin, cout), dset)
+        g = self._graphs.get(key)
+        if g is None and capture:
+            self._bind_set(dset)
+            with span("graph_capture", steps=n):
+                g = self.engine._capture_pipe(pos, n, cin, cout)
+            self._graphs[key] = g
+        return g
+
+    def prepare(self, steps_hint=()):
+        if not self._chains():
+            return super().prepare(steps_hint)
+        bpe = self.engine.batches_per_epoch
+        cursor = self.engine._host_cursor
+        carried = None          # every capture below drops what the engine carries, so the first chunk starts afresh
+        keys = []
+        for n in steps_hint:
+            for k in self._schedule(cursor, n):
+                pos = cursor % bpe
+                cin, cout = carried == pos and pos > 0, pos + k < bpe
+                key = (pos, k, cin, cout, self._set_at(cursor))
+                if key not in keys:
+                    keys.append(key)
+                carried = pos + k if cout else None
+                cursor += k
+        live_set = self._bound_set
+        for pos, k, cin, cout, st in keys:
+            self._pipe_graph(pos, k, cin, cout, st)
+        self._bind_set(live_set)
+
+    def run_steps(self, n: int):
+        if not self._chains():
+            return super().run_steps(n)
+        eng = self.engine
+        bpe = eng.batches_per_epoch
+        for k in self._schedule(eng._host_cursor, n):
+            cur = eng._host_cursor
+            if cur % bpe == 0 and cur > 0:
+                with span("shuffle_epoch"):
+                    self.ds.shuffle_epoch()
+                eng.invalidate_carry()
+            self._bind_set(getattr(self.ds, "active", 0))
+            pos = cur % bpe
+            cin, cout = eng.carried_to == pos and pos > 0, pos + k < bpe
+            g = self._pipe_graph(pos, k, cin, cout, self._bound_set, capture=False) if cin else None
+            if g is None:
+                # (capturing runs warm-up steps over whatever was carried: a chunk captured now starts afresh)
+                cin = False
+                g = self._pipe_graph(pos, k, False, cout, self._bound_set)
+            with span("chunk_replay", steps=k):
+                g.replay()
+            eng.note_carry(pos + k if cout else None)
+            eng._host_cursor += k
+            self.steps_done += k
+            if hasattr(self.ds, "stage_ahead"):
+                self.ds.stage_ahead()
 
     def describe(self):
         how = "1 launch/step (backward of step t + forward of step t+1 in one kernel)" if self.pipelined \

@@ -348,6 +348,41 @@ def test_drawing_the_next_order_late_does_not_change_the_orders():
         assert torch.equal(a.x_epoch, b.x_epoch) and torch.equal(a.y_epoch, b.y_epoch), epoch
 
 
+@pytest.mark.parametrize("windows", [(5, 5, 2, 5, 5), (1, 1, 3, 7, 1, 2), (12, 12), (4, 3, 5, 1, 11)])
+def test_chained_one_launch_chunks_give_the_results_of_chunks_that_start_afresh(windows, monkeypatch):
+    """A chunk that starts where the previous one ended (forward pass and transposed W1 carried over: no prologue)
+    against the same windows with every chunk starting afresh, and both against the plain two-launch step."""
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.rand(1230, 784, generator=g), torch.eye(10)[torch.randint(0, 10, (1230,), generator=g)]
+
+    def run(carry, pipelined=True):
+        monkeypatch.setenv("DTF_PIPE_CARRY", "1" if carry else "0")
+        ds = DeviceDataset(x, y, DEV, 100, seed=1)
+        tr = build_replica_trainer(mode="single", device=DEV, dataset=ds, batch=100, lr=0.01, seed=2, chunk=12,
+                                   pipelined=pipelined)
+        tr.prepare(windows[:3])                 # some graphs ahead of time, the rest captured on the way
+        costs = []
+        for k in windows:
+            tr.run_steps(k)
+            costs.append(tr.last_loss())
+        torch.cuda.synchronize()
+        return tr, costs
+
+    a, ca = run(True)
+    b, cb = run(False)
+    c, cc = run(False, pipelined=False)
+    assert a.global_step_value() == b.global_step_value() == c.global_step_value() == sum(windows)
+    if windows != (12, 12):                     # (two whole epochs: nothing to chain)
+        assert any(k[2] in (("carry", True, True), ("carry", True, False)) for k in a._graphs), "no chunk chained"
+    for other, co in ((b, cb), (c, cc)):
+        # (separate runs: the logit partial sums meet through float atomics, whose order varies run to run)
+        torch.testing.assert_close(a.params, other.params, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(torch.tensor(ca), torch.tensor(co), rtol=2e-4, atol=2e-5)
+
+
 def test_window_results_fetched_behind_the_next_window_equal_the_blocking_reads():
     from distributed_tensorflow_amd.data import DeviceDataset
     from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
