@@ -26,6 +26,7 @@ same semantics, which is both the soft-placement fallback and the test oracle.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -443,6 +444,8 @@ class MLPEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.chunk_pipelined(pos, n, carry_in, carry_out)
+        if os.environ.get("DTF_GRAPH_UPLOAD", "1") != "0":
+            hb.graph_upload(graph)      # the first replay may sit inside somebody's timed region
         return graph
 
     def reset_step_workspace(self, parity: int = 0):

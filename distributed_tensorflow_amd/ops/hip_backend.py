@@ -453,6 +453,24 @@ def enable_peer_access(device: torch.device, peer: torch.device) -> None:
         _check(require().dtf_enable_peer_access(int(a), int(b)), f"peer access cuda:{a} -> cuda:{b}")
 
 
+_hiprt = None
+
+
+def graph_upload(graph: "torch.cuda.CUDAGraph") -> bool:
+    """Have the runtime place an instantiated graph on the device now (``hipGraphUpload``) instead of during its
+    first launch.  False when the handle or the entry point is not available (nothing is lost: the first replay does it)."""
+    global _hiprt
+    try:
+        exec_handle = graph.raw_cuda_graph_exec()
+        if _hiprt is None:
+            _hiprt = C.CDLL("libamdhip64.so")
+            _hiprt.hipGraphUpload.argtypes = [C.c_void_p, C.c_void_p]
+            _hiprt.hipGraphUpload.restype = C.c_int
+        return _hiprt.hipGraphUpload(exec_handle, _stream()) == 0
+    except Exception:  # noqa: BLE001 — an optimisation only
+        return False
+
+
 def streams_independent(a: "torch.cuda.Stream", b: "torch.cuda.Stream", timeout_us: int = 20000) -> bool:
     """Whether a kernel on ``b`` runs while a kernel on ``a`` waits for it (both directions are checked): False when the
     two streams of this process share a hardware queue."""
