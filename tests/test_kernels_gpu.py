@@ -383,6 +383,36 @@ def test_chained_one_launch_chunks_give_the_results_of_chunks_that_start_afresh(
         torch.testing.assert_close(torch.tensor(ca), torch.tensor(co), rtol=2e-4, atol=2e-5)
 
 
+def test_what_a_chunk_carries_is_dropped_by_anything_else_that_steps_the_engine():
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
+
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.rand(1230, 784, generator=g), torch.eye(10)[torch.randint(0, 10, (1230,), generator=g)]
+    tx, ty = x[:200].to(DEV), y[:200].to(DEV)
+
+    def trainer():
+        ds = DeviceDataset(x, y, DEV, 100, seed=1)
+        return build_replica_trainer(mode="single", device=DEV, dataset=ds, batch=100, lr=0.01, seed=2, chunk=12)
+
+    a, b = trainer(), trainer()
+    a.run_steps(3)
+    assert a.engine.carried_to == 3
+    a.evaluate(tx, ty)                                  # reads the parameters only
+    assert a.engine.carried_to == 3
+    a.engine.step_fused(3)                              # a two-launch step behind the trainer's back (batch 3)
+    a.engine.advance(1)
+    assert a.engine.carried_to is None
+    a.run_steps(4)                                      # starts afresh at batch 4, chains from there
+    assert a.engine.carried_to == 8
+    a.engine.invalidate_carry()
+    a.run_steps(4)                                      # the last chunk of the epoch leaves nothing behind
+    assert a.engine.carried_to is None and a.global_step_value() == 12
+    b.run_steps(12)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a.params, b.params, rtol=2e-4, atol=2e-5)
+
+
 def test_window_results_fetched_behind_the_next_window_equal_the_blocking_reads():
     from distributed_tensorflow_amd.data import DeviceDataset
     from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer
