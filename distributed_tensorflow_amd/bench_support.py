@@ -609,6 +609,10 @@ def _result(n, steps, warmup, elapsed, parallelism, source, use_cpu, device, ran
         # graph executor's op-by-op fallback for unrecognised graphs is never part of this benchmark
         "generic_steps": 0,
         "multi_gpu_measured": bool(ranks_seen > 1 and not use_cpu and os.environ.get("DTF_BENCH_SHARE_GPU") != "1"),
+        # what the K timed steps are, for reading ms_per_step at small K next to sec_per_epoch / steps_per_epoch
+        "timed_region": ("run_steps(%d) between two synchronisations: hipGraph replays launched from an idle device "
+                         "(launch and wake-up latency of about 20 us included)" % steps) if not use_cpu
+                        else "run_steps(%d)" % steps,
     }
     out.update(extra)
     return out
