@@ -232,5 +232,12 @@ extern "C" int dtf_gather_gram(const float* src, const int64_t* perm, float* dst
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
+// Workgroups of the kernel that one CU holds at a time, as the runtime computes it (registers, LDS, wave slots).
+extern "C" int dtf_debug_gram_blocks_per_cu(void) {
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gram_kernel, kThreads, 0) != hipSuccess) return -1;
+  return n;
+}
+
 // Timing experiments: run only some parts of the kernel (results are then wrong); 7 restores the full kernel.
 extern "C" void dtf_debug_set_gram_parts(int parts) { g_gram_parts = parts; }
