@@ -14,7 +14,7 @@ for f in files:
             "bwd_tile16_xg" if "bwd_tile16_xg" in name else \
             "bwd_tile16" if "bwd_tile16" in name else "gather_rows" if "gather_rows" in name else \
             "range_pull" if "range_pull" in name else "shard_push" if "shard_push" in name else \
-            "gather_gram" if "gather_gram" in name else "eval_fused" if "eval_fused" in name else "sum_apply" if "sum_apply" in name else None
+            "gemm_f32" if "gemm_f32" in name else "gather_gram" if "gather_gram" in name else "eval_fused" if "eval_fused" in name else "sum_apply" if "sum_apply" in name else None
         if short is None:
             continue
         k = (short, r["Counter_Name"])

@@ -176,6 +176,28 @@ int dtf_xgmi_push_sgd(const uint64_t* shards, int world, int64_t chunk, const fl
 int dtf_xgmi_fill(void* p, int byte, int64_t bytes);
 int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int world, float* local, void* stream);
 
+// --- dense layers of any shape (gemm.hip) ----------------------------------------------------------------------
+// C[M][N] = epilogue(sum_k opA(m,k) opB(k,n)) on the fp32 matrix cores; leading dimensions in floats.
+#define DTF_GEMM_NN 0        // A[m*lda + k], B[k*ldb + n]
+#define DTF_GEMM_NT 1        // A[m*lda + k], B[n*ldb + k]
+#define DTF_GEMM_TN 2        // A[k*lda + m], B[k*ldb + n]
+#define DTF_EPI_NONE 0       // C = scale * acc
+#define DTF_EPI_BIAS_ACT 1   // C = act(acc + bias[n])      (bias may be null; act DTF_ACT_* or DTF_ACT_NONE)
+#define DTF_EPI_ACT_BWD 2    // C = acc * act'(aux[m*ldaux + n])   with act' written through the activation's OUTPUT
+#define DTF_EPI_SGD 3        // C -= lr[0] * scale * acc
+// tile: 0 = chosen from the shape, 64 or 128 = forced (tuning and tests).
+int dtf_gemm_f32(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K, int64_t lda,
+                 int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux, int64_t ldaux,
+                 const float* lr, float scale, int tile, void* stream);
+// out[n] = scale * sum_m z[m*ldz + n]  (mode DTF_EPI_NONE)  or  out[n] -= lr[0] * scale * sum  (mode DTF_EPI_SGD)
+int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out, int mode, float scale, const float* lr,
+               void* stream);
+// Softmax cross-entropy over logits [M][C] against (soft) labels [M][C]: loss_sum += sum of the row losses, correct +=
+// rows whose argmax matches the labels' (both accumulated, either may be null), dz = grad_scale * dLoss_row/dlogits
+// (null: forward only), row_loss[m] (may be null).
+int dtf_softmax_xent(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                     float* loss_sum, int32_t* correct, float* row_loss, void* stream);
+
 int dtf_abi_sizeof(int which);   // sizeof of DtfMlpDesc (0), DtfPipeDesc (1), DtfXgDesc (2)
 const char* dtf_hip_build_info(void);
 

@@ -11,6 +11,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DTF_ACT_SIGMOID 0
 #define DTF_ACT_RELU 1
+#define DTF_ACT_TANH 2      // dense-layer kernels only (gemm.hip)
+#define DTF_ACT_NONE (-1)   // dense-layer kernels only: a linear layer
 
 // Error codes returned by every extern "C" entry point (0 = success).
 #define DTF_OK 0
@@ -21,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float dtf_act_fwd(float z, int act) {
   if (act == DTF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-z));
+  if (act == DTF_ACT_TANH) return tanhf(z);
   return fmaxf(z, 0.0f);
 }
 
@@ -28,6 +31,8 @@ __device__ __forceinline__ float dtf_act_fwd(float z, int act) {
 // pre-activation never has to be kept.
 __device__ __forceinline__ float dtf_act_bwd(float a, int act) {
   if (act == DTF_ACT_SIGMOID) return a * (1.0f - a);
+  if (act == DTF_ACT_TANH) return 1.0f - a * a;
+  if (act == DTF_ACT_NONE) return 1.0f;
   return a > 0.0f ? 1.0f : 0.0f;
 }
 

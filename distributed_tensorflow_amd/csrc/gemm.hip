@@ -1,0 +1,430 @@
+// Dense-layer kernels for models other than the reference's 784-100-10 network: an fp32 GEMM family on the gfx950
+// matrix cores with the layer's element-wise work in its epilogue, a column sum (bias gradients) and a softmax
+// cross-entropy head.  Together they are every launch of a fully connected stack of any depth and width
+// (models/dense.py) and the MatMul of the graph executor's op-by-op path (ops/gemm.py).
+//
+//   C[M][N] = epilogue( sum_k opA(m, k) * opB(k, n) )
+//
+//   layout NN   A[m * lda + k]   B[k * ldb + n]      forward            a = act(x W + b)
+//   layout NT   A[m * lda + k]   B[n * ldb + k]      input gradient     dx = (dz W^T) * act'(a)
+//   layout TN   A[k * lda + m]   B[k * ldb + n]      weight gradient    W -= lr * x^T dz      (or dW = x^T dz)
+//
+// (the MatMul, BiasAdd, Sigmoid / Relu, their gradients and ApplyGradientDescent of a graph built like
+// tfdist_between.py:55-66, for any number of layers).
+//
+// Tiling.  A workgroup of four waves owns a BM x BN tile of C (128 x 128, or 64 x 64 when the larger tile would leave
+// CUs idle) and walks K in chunks of 32.  Both operands of a chunk sit in LDS as [k-quad][row or column][4 floats]
+// images, so that lane (i = l & 15, q = l >> 4) reads the four k of k-quad 4 ms + q for row / column i with ONE
+// ds_read_b128 (16 lanes = 256 contiguous bytes: no bank conflict) and feeds them to four v_mfma_f32_16x16x4_f32: MFMA s
+// of macro-step ms contracts k = 16 ms + 4 q + s.  A wave computes a (BM/2) x (BN/2) quadrant: 8 reads for 64 MFMAs per
+// macro-step with the 128-tile.  Two chunk images: the loads of chunk c + 1 are requested before chunk c is multiplied
+// and written to the other image after it; one barrier per chunk.
+//
+// Staging.  An operand whose k runs along memory (A of NN / NT, B of NT) arrives as 16-byte loads, 8 rows x 8 k-quads
+// per wave-instruction (whole 128-byte lines), and is stored as it comes; an operand whose k is strided (B of NN, both of
+// TN) arrives as four coalesced dwords per (k-quad, column) slot and is transposed in registers on its way to the 16-byte
+// LDS store.  Rows, columns and k past the edge are clamped on the way in and zeroed on the way to LDS, so any M, N, K
+// works; operands that are not 16-byte aligned take dword loads.
+//
+// Placement.  Workgroup ids are relabelled so that the workgroups of one XCD (ids equal modulo 8) own a contiguous run
+// of tiles, ordered in groups of 8 tile rows: the tiles in flight on an XCD share a few row panels of A and column panels
+// of B in that XCD's L2.
+#include "dtf_api.h"
+#include "dtf_common.h"
+#include "dtf_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kKQ = 8;                // k-quads per chunk
+constexpr int kChunk = 4 * kKQ;       // k per chunk
+constexpr int kGroupM = 8;            // tile rows per group of the tile order
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int epi, act;
+  const float* bias;       // DTF_EPI_BIAS_ACT: [N] (may be null: no bias)
+  const float* aux;        // DTF_EPI_ACT_BWD: activation outputs [M][ldaux]
+  long ldaux;
+  const float* lr;         // DTF_EPI_SGD: device learning rate
+  float scale;             // DTF_EPI_SGD: C -= lr * scale * acc;  DTF_EPI_NONE: C = scale * acc
+  int tiles_m, tiles_n;
+};
+
+// What one thread moves per chunk for one operand: NS = R / 32 slots of four k each.  With the 64-tile, chunks that lie
+// inside K take loads without clamps and tiles that lie inside the operand take LDS stores without masks (both
+// wave-uniform tests); with the 128-tile the second copy of the staging code costs more registers than the kernel has
+// (measured: 16 - 42 spilled registers, 108 -> 86 TFLOP/s), so there every chunk takes the clamped form.
+template <int R, bool KC, bool VEC>
+struct Stager {
+  static constexpr int NS = R / 32;
+  static constexpr bool kFast = R <= 64;
+  const float* p[NS];      // address of (row or column of the slot, k = 4 kq)
+  int lds[NS], kq[NS];
+  bool ok[NS];
+  f32x4 v[NS];
+  long ld;
+  int K;
+  bool interior;
+
+  __device__ __forceinline__ void init(const float* base, long ld_, int rows, int r0, int K_, int tid) {
+    ld = ld_;
+    K = K_;
+    interior = r0 + R <= rows;
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      int r;
+      if (KC) {          // 8 rows x 8 k-quads per wave-instruction
+        r = 8 * (wave + 4 * j) + (lane & 7);
+        kq[j] = lane >> 3;
+      } else {           // consecutive lanes walk the rows / columns of one k-quad
+        const int slot = tid + kThreads * j;
+        r = slot % R;
+        kq[j] = slot / R;
+      }
+      ok[j] = r0 + r < rows;
+      const long rr = ok[j] ? r0 + r : rows - 1;
+      p[j] = KC ? base + rr * ld + 4 * kq[j] : base + rr + (long)(4 * kq[j]) * ld;
+      lds[j] = (kq[j] * R + r) * 4;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0) {
+    if (kFast && k0 + kChunk <= K) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (KC && VEC) {
+          v[j] = *reinterpret_cast<const f32x4*>(p[j] + k0);
+        } else {
+          const float* b = KC ? p[j] + k0 : p[j] + (long)k0 * ld;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[j][s] = KC ? b[s] : b[s * ld];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int k = k0 + 4 * kq[j];
+        if (KC && VEC) {          // (K is a multiple of 4 here: a quad is inside or outside as a whole)
+          v[j] = *reinterpret_cast<const f32x4*>(p[j] + (k < K ? (long)k0 : -(long)(4 * kq[j])));
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const long rel = (k + s < K ? k + s : 0) - 4 * kq[j];       // k clamped, relative to p[j]
+            v[j][s] = KC ? p[j][rel] : p[j][rel * ld];
+          }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void write(int k0, float* img) const {
+    if (kFast && interior && k0 + kChunk <= K) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds[j]) = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const int k = k0 + 4 * kq[j];
+        f32x4 o = v[j];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = (ok[j] && k + s < K) ? o[s] : 0.f;
+        *reinterpret_cast<f32x4*>(img + lds[j]) = o;
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int LAYOUT, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
+  constexpr bool AK = LAYOUT != DTF_GEMM_TN, BK = LAYOUT == DTF_GEMM_NT;
+  constexpr int TM = BM / 32, TN = BN / 32;            // 16 x 16 blocks per wave in each direction
+  constexpr int kAs = kKQ * BM * 4, kBs = kKQ * BN * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][kAs]
+  float* Bs = smem + 2 * kAs;        // [2][kBs]
+
+  // ---- which tile (see "Placement") ----
+  const int T = a.tiles_m * a.tiles_n;
+  int tile;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, qq = T >> 3, rr = T & 7;
+    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+  }
+  const int group_sz = kGroupM * a.tiles_n, g = tile / group_sz, first_m = g * kGroupM;
+  const int gm = a.tiles_m - first_m < kGroupM ? a.tiles_m - first_m : kGroupM;
+  const int in_group = tile - g * group_sz;
+  const int m0 = (first_m + in_group % gm) * BM, n0 = (in_group / gm) * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+  Stager<BM, AK, VEC> sa;
+  Stager<BN, BK, VEC> sb;
+  sa.init(a.A, a.lda, a.M, m0, a.K, tid);
+  sb.init(a.B, a.ldb, a.N, n0, a.K, tid);
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < TN; ++bj) acc[bi][bj] = zero4;
+
+  const int nchunks = (a.K + kChunk - 1) / kChunk;
+  // operand registers of one macro-step: [0] = macro-step 0 of a chunk, [1] = macro-step 1
+  f32x4 av[2][TM], bv[2][TN];
+  auto read_ops = [&](const float* Ac, const float* Bc, int ms, f32x4 (&ar)[TM], f32x4 (&br)[TN]) {
+    const int kq = 4 * ms + q;
+#pragma unroll
+    for (int bi = 0; bi < TM; ++bi) ar[bi] = *reinterpret_cast<const f32x4*>(Ac + (kq * BM + wm0 + 16 * bi + i16) * 4);
+#pragma unroll
+    for (int bj = 0; bj < TN; ++bj) br[bj] = *reinterpret_cast<const f32x4*>(Bc + (kq * BN + wn0 + 16 * bj + i16) * 4);
+  };
+  auto multiply = [&](const f32x4 (&ar)[TM], const f32x4 (&br)[TN], int s0, int s1) {
+#pragma unroll
+    for (int s = s0; s < s1; ++s)
+#pragma unroll
+      for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < TN; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[bi][s], br[bj][s], acc[bi][bj], 0, 0, 0);
+  };
+
+  // Order of one chunk (so that a wave has matrix work queued whenever it waits for memory, LDS or the barrier):
+  //   operands of macro-step 1 requested from LDS | macro-step 0 multiplied | chunk c+1 (loaded a chunk ago) written to
+  //   the other image, chunk c+2 requested from memory | three quarters of macro-step 1 | barrier | operands of chunk
+  //   c+1's macro-step 0 requested from LDS | the last quarter of macro-step 1.
+  // Image (c+1) & 1 is written while everybody reads image c & 1, and read only after the barrier that follows the
+  // writes; its previous contents (chunk c-1) were last read before the barrier of chunk c-1.
+  sa.issue(0);
+  sb.issue(0);
+  sa.write(0, As);
+  sb.write(0, Bs);
+  if (nchunks > 1) {
+    sa.issue(kChunk);
+    sb.issue(kChunk);
+  }
+  __syncthreads();
+  read_ops(As, Bs, 0, av[0], bv[0]);
+  for (int c = 0; c < nchunks; ++c) {
+    const float* Ac = As + (c & 1) * kAs;
+    const float* Bc = Bs + (c & 1) * kBs;
+    float* An = As + ((c + 1) & 1) * kAs;
+    float* Bn = Bs + ((c + 1) & 1) * kBs;
+    const bool more = c + 1 < nchunks;
+    read_ops(Ac, Bc, 1, av[1], bv[1]);
+    multiply(av[0], bv[0], 0, 4);
+    if (more) {
+      sa.write((c + 1) * kChunk, An);
+      sb.write((c + 1) * kChunk, Bn);
+      if (c + 2 < nchunks) {
+        sa.issue((c + 2) * kChunk);
+        sb.issue((c + 2) * kChunk);
+      }
+    }
+    multiply(av[1], bv[1], 0, 3);
+    __syncthreads();
+    if (more) read_ops(An, Bn, 0, av[0], bv[0]);
+    multiply(av[1], bv[1], 3, 4);
+  }
+
+  // ---- epilogue: register r of block (bi, bj) is C[m0 + wm0 + 16 bi + 4 q + r][n0 + wn0 + 16 bj + i16] ----
+  const float step = a.epi == DTF_EPI_SGD ? a.lr[0] * a.scale : a.scale;
+#pragma unroll
+  for (int bj = 0; bj < TN; ++bj) {
+    const int n = n0 + wn0 + 16 * bj + i16;
+    if (n >= a.N) continue;
+    const float bias = (a.epi == DTF_EPI_BIAS_ACT && a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm0 + 16 * bi + 4 * q + r;
+        if (m >= a.M) continue;
+        float* c = a.C + (long)m * a.ldc + n;
+        const float s = acc[bi][bj][r];
+        if (a.epi == DTF_EPI_BIAS_ACT)
+          *c = a.act < 0 ? s + bias : dtf_act_fwd(s + bias, a.act);
+        else if (a.epi == DTF_EPI_ACT_BWD)
+          *c = s * dtf_act_bwd(a.aux[(long)m * a.ldaux + n], a.act);
+        else if (a.epi == DTF_EPI_SGD)
+          *c -= step * s;
+        else
+          *c = step * s;
+      }
+  }
+}
+
+template <int BM, int BN, int LAYOUT, bool VEC>
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  constexpr int bytes = 2 * kKQ * (BM + BN) * 4 * (int)sizeof(float);
+  static unsigned long long configured = 0;            // one bit per device: the attribute belongs to the device's copy
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
+  if (dev >= 64 || !((configured >> dev) & 1ull)) {
+    if (hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, LAYOUT, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bytes) != hipSuccess)
+      return DTF_ERR_LAUNCH;
+    if (dev < 64) configured |= 1ull << dev;
+  }
+  GemmArgs b = a;
+  b.tiles_m = (a.M + BM - 1) / BM;
+  b.tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), dim3(b.tiles_m * b.tiles_n), dim3(kThreads), bytes, stream,
+                     b);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+template <int LAYOUT, bool VEC>
+int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
+  // the 128-tile once it fills the chip (a workgroup per CU), the 64-tile below that
+  const long big = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (tile == 128 || (tile == 0 && big >= 256)) return launch_gemm<128, 128, LAYOUT, VEC>(a, stream);
+  return launch_gemm<64, 64, LAYOUT, VEC>(a, stream);
+}
+
+// ---- column sums: out[n] (op)= scale * sum_m z[m][n] -------------------------------------------------------------
+// A workgroup owns 64 columns; its four waves walk the rows four apart (every load a 256-byte row segment) and meet in LDS.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ z, long ldz, int M, int N, float* out,
+                                                     int mode, float scale, const float* lr) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int m = wave;
+    for (; m + 4 < M; m += 8) {
+      s0 += z[(long)m * ldz + n];
+      s1 += z[(long)(m + 4) * ldz + n];
+    }
+    if (m < M) s0 += z[(long)m * ldz + n];
+  }
+  part[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (mode == DTF_EPI_SGD)
+      out[n] -= lr[0] * scale * s;
+    else
+      out[n] = scale * s;
+  }
+}
+
+// ---- softmax cross-entropy head over logits [M][C] -----------------------------------------------------------------
+//   loss_sum += sum_m -sum_c y log softmax(z)     correct += #{m : argmax z == argmax y}      (accumulated)
+//   dz[m][c] = grad_scale * (softmax(z)[m][c] * sum_c' y[m][c'] - y[m][c])                      (dz may be null)
+// (the Softmax, Log, Mul, Sum, Mean, ArgMax, Equal nodes of tfdist_between.py:59-70 and their gradients, with the
+// logarithm taken of the shifted exponentials' sum instead of the probability.)  A wave per row, 4 rows per workgroup.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                           int M, int C, float* dz, float grad_scale, float* loss_sum,
+                                                           int* correct, float* row_loss) {
+  __shared__ float wl[4];
+  __shared__ int wc[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  float loss = 0.f;
+  int hit = 0;
+  if (m < M) {
+    const float* zr = z + (long)m * C;
+    const float* yr = y + (long)m * C;
+    float mx = -INFINITY, ymx = -INFINITY;
+    int zi = 0x7fffffff, yi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = zr[c], t = yr[c];
+      if (v > mx) { mx = v; zi = c; }
+      if (t > ymx) { ymx = t; yi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {      // ties go to the smallest index (tf.argmax)
+      const float ov = __shfl_xor(mx, o, 64), oy = __shfl_xor(ymx, o, 64);
+      const int oi = __shfl_xor(zi, o, 64), oyi = __shfl_xor(yi, o, 64);
+      if (ov > mx || (ov == mx && oi < zi)) { mx = ov; zi = oi; }
+      if (oy > ymx || (oy == ymx && oyi < yi)) { ymx = oy; yi = oyi; }
+    }
+    float se = 0.f, ys = 0.f, yz = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float t = yr[c];
+      se += expf(zr[c] - mx);
+      ys += t;
+      yz += t * (zr[c] - mx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      se += __shfl_xor(se, o, 64);
+      ys += __shfl_xor(ys, o, 64);
+      yz += __shfl_xor(yz, o, 64);
+    }
+    const float lse = logf(se);
+    loss = ys * lse - yz;                    // -sum_c y (z - mx - lse)
+    hit = zi == yi ? 1 : 0;
+    if (dz != nullptr) {
+      const float inv = 1.f / se;
+      for (int c = lane; c < C; c += 64) dz[(long)m * C + c] = grad_scale * (expf(zr[c] - mx) * inv * ys - yr[c]);
+    }
+    if (row_loss != nullptr && lane == 0) row_loss[m] = loss;
+  }
+  if (lane == 0) {
+    wl[wave] = loss;
+    wc[wave] = hit;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (loss_sum != nullptr) atomicAdd(loss_sum, (wl[0] + wl[1]) + (wl[2] + wl[3]));
+    if (correct != nullptr) atomicAdd(correct, wc[0] + wc[1] + wc[2] + wc[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int dtf_gemm_f32(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K,
+                            int64_t lda, int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux,
+                            int64_t ldaux, const float* lr, float scale, int tile, void* stream) {
+  if (A == nullptr || B == nullptr || C == nullptr) return DTF_ERR_NULL;
+  if (M < 1 || N < 1 || K < 1 || ldc < N) return DTF_ERR_SHAPE;
+  if (layout < DTF_GEMM_NN || layout > DTF_GEMM_TN || epi < DTF_EPI_NONE || epi > DTF_EPI_SGD) return DTF_ERR_SHAPE;
+  if ((layout == DTF_GEMM_TN ? lda < M : lda < K) || (layout == DTF_GEMM_NT ? ldb < K : ldb < N)) return DTF_ERR_SHAPE;
+  if (epi == DTF_EPI_ACT_BWD && (aux == nullptr || ldaux < N)) return DTF_ERR_NULL;
+  if (epi == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
+  if (tile != 0 && tile != 64 && tile != 128) return DTF_ERR_SHAPE;
+  GemmArgs a{};
+  a.A = A; a.B = B; a.C = C;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.epi = epi; a.act = act;
+  a.bias = bias; a.aux = aux; a.ldaux = ldaux;
+  a.lr = lr; a.scale = scale;
+  // 16-byte loads along k need K, the leading dimension and the base address to be multiples of four floats (a
+  // compile-time variant: every operand of the layout whose k runs along memory must qualify)
+  const bool vecA = (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
+  const bool vecB = (K & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (layout == DTF_GEMM_NN) return vecA ? launch_layout<DTF_GEMM_NN, true>(a, tile, s) : launch_layout<DTF_GEMM_NN, false>(a, tile, s);
+  if (layout == DTF_GEMM_NT)
+    return vecA && vecB ? launch_layout<DTF_GEMM_NT, true>(a, tile, s) : launch_layout<DTF_GEMM_NT, false>(a, tile, s);
+  return launch_layout<DTF_GEMM_TN, false>(a, tile, s);
+}
+
+extern "C" int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out, int mode, float scale, const float* lr,
+                          void* stream) {
+  if (z == nullptr || out == nullptr) return DTF_ERR_NULL;
+  if (M < 1 || N < 1 || ldz < N) return DTF_ERR_SHAPE;
+  if (mode != DTF_EPI_NONE && mode != DTF_EPI_SGD) return DTF_ERR_SHAPE;
+  if (mode == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), z, (long)ldz, M,
+                     N, out, mode, scale, lr);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_softmax_xent(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                                float* loss_sum, int32_t* correct, float* row_loss, void* stream) {
+  if (logits == nullptr || labels == nullptr) return DTF_ERR_NULL;
+  if (M < 1 || C < 1) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+                     labels, M, C, dz, grad_scale, loss_sum, correct, row_loss);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}

@@ -1,2 +1,4 @@
-"""Model families.  The reference has exactly one: the 784-100-10 MLP."""
+"""Model families: the reference's 784-100-10 MLP (one or two launches per step) and fully connected stacks of any
+depth and width on the dense-layer kernels."""
+from .dense import DenseStackEngine  # noqa: F401
 from .mlp import MLPEngine  # noqa: F401

@@ -140,6 +140,11 @@ def _declare(lib: C.CDLL) -> None:
                  "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
                  "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
         getattr(lib, name).restype = C.c_int
+    lib.dtf_gemm_f32.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, i64, vp, f32, i32, vp]
+    lib.dtf_colsum.argtypes = [vp, i64, i32, i32, vp, i32, f32, vp, vp]
+    lib.dtf_softmax_xent.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]
+    for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent"):
+        getattr(lib, name).restype = C.c_int
     lib.dtf_debug_force_generic_path.argtypes = [i32]
     lib.dtf_debug_force_generic_path.restype = None
     lib.dtf_debug_set_fwd_tile8.argtypes = [i32]
@@ -283,6 +288,100 @@ def dw_gemm(x, dz, out: Optional[torch.Tensor] = None, mode: int = 0, scale: flo
     _check(lib.dtf_dw_gemm(_ptr(x), _ptr(dz), _ptr(out), M, K, H, mode, float(scale), _ptr(lr), _stream()),
            "dtf_dw_gemm")
     return out
+
+
+GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_BIAS_ACT, EPI_ACT_BWD, EPI_SGD = 0, 1, 2, 3
+ACT_NONE = -1
+
+
+def _f32_2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise HipKernelError(f"{name} must be a 2-D float32 CUDA tensor with contiguous rows, got {t.dtype} "
+                             f"{tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t
+
+
+def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EPI_NONE, act: int = ACT_NONE,
+         bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, lr: Optional[torch.Tensor] = None,
+         scale: float = 1.0, tile: int = 0) -> torch.Tensor:
+    """``out = epilogue(op(A) @ op(B))`` on the fp32 matrix cores (csrc/gemm.hip).
+
+    layout ``GEMM_NN``: A [M,K], B [K,N]; ``GEMM_NT``: A [M,K], B [N,K]; ``GEMM_TN``: A [K,M], B [K,N].  Operands are
+    row-major with contiguous rows (row strides may exceed the row length).  Epilogues: ``EPI_NONE`` ``scale * acc``;
+    ``EPI_BIAS_ACT`` ``act(acc + bias)``; ``EPI_ACT_BWD`` ``acc * act'(aux)`` (aux = the activation's output);
+    ``EPI_SGD`` ``out -= lr * scale * acc`` (lr: one-element device tensor)."""
+    lib = require()
+    _f32_2d(A, "A"), _f32_2d(B, "B")
+    if layout == GEMM_NN:
+        (M, K), (K2, N) = A.shape, B.shape
+    elif layout == GEMM_NT:
+        (M, K), (N, K2) = A.shape, B.shape
+    elif layout == GEMM_TN:
+        (K, M), (K2, N) = A.shape, B.shape
+    else:
+        raise HipKernelError(f"gemm: unknown layout {layout}")
+    if K != K2:
+        raise HipKernelError(f"gemm: inner dimensions differ, A{tuple(A.shape)} B{tuple(B.shape)} layout {layout}")
+    if out is None:
+        if epi == EPI_SGD:
+            raise HipKernelError("gemm: the SGD epilogue updates `out` in place")
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    _f32_2d(out, "out")
+    if tuple(out.shape) != (M, N) or out.device != A.device or B.device != A.device:
+        raise HipKernelError(f"gemm: output {tuple(out.shape)} on {out.device} for a {M}x{N} product on {A.device}")
+    if bias is not None and (_f32c(bias, "bias").numel() != N or bias.device != A.device):
+        raise HipKernelError("gemm: bias must have one element per output column")
+    if epi == EPI_ACT_BWD and (aux is None or tuple(_f32_2d(aux, "aux").shape) != (M, N) or aux.device != A.device):
+        raise HipKernelError("gemm: the activation-gradient epilogue needs the activation's output, shaped like out")
+    if epi == EPI_SGD and (lr is None or _f32c(lr, "lr").numel() != 1):
+        raise HipKernelError("gemm: the SGD epilogue needs a one-element device learning rate")
+    _check(lib.dtf_gemm_f32(layout, epi, _ptr(A), _ptr(B), _ptr(out), M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                            int(act), _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0, _ptr(lr),
+                            float(scale), int(tile), _stream()), "dtf_gemm_f32")
+    return out
+
+
+def colsum(z, out: Optional[torch.Tensor] = None, *, sgd: bool = False, lr: Optional[torch.Tensor] = None,
+           scale: float = 1.0) -> torch.Tensor:
+    """``out = scale * z.sum(0)`` or, with ``sgd``, ``out -= lr * scale * z.sum(0)`` (bias gradients)."""
+    lib = require()
+    _f32_2d(z, "z")
+    M, N = z.shape
+    if out is None:
+        if sgd:
+            raise HipKernelError("colsum: the SGD form updates `out` in place")
+        out = torch.empty((N,), device=z.device, dtype=torch.float32)
+    if _f32c(out, "out").numel() != N or out.device != z.device:
+        raise HipKernelError("colsum: one output element per column")
+    if sgd and (lr is None or _f32c(lr, "lr").numel() != 1):
+        raise HipKernelError("colsum: the SGD form needs a one-element device learning rate")
+    _check(lib.dtf_colsum(_ptr(z), z.stride(0), M, N, _ptr(out), EPI_SGD if sgd else EPI_NONE, float(scale), _ptr(lr),
+                          _stream()), "dtf_colsum")
+    return out
+
+
+def softmax_xent(logits, labels, *, dz: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+                 loss_sum: Optional[torch.Tensor] = None, correct: Optional[torch.Tensor] = None,
+                 row_loss: Optional[torch.Tensor] = None):
+    """Softmax cross-entropy head: accumulates the sum of the row losses into ``loss_sum`` (float32[1]) and the
+    number of rows classified like their labels into ``correct`` (int32[1]); ``dz`` (shaped like logits) receives
+    ``grad_scale * d(row loss)/d(logits)``; ``row_loss`` (float32[M]) the per-row losses."""
+    lib = require()
+    _f32c(logits, "logits"), _f32c(labels, "labels")
+    if logits.dim() != 2 or labels.shape != logits.shape or labels.device != logits.device:
+        raise HipKernelError("softmax_xent: logits and labels must be equally shaped 2-D tensors on one device")
+    M, Cn = logits.shape
+    if dz is not None and (_f32c(dz, "dz").shape != logits.shape or dz.device != logits.device):
+        raise HipKernelError("softmax_xent: dz must be shaped like the logits")
+    if loss_sum is not None and (_f32c(loss_sum, "loss_sum").numel() != 1):
+        raise HipKernelError("softmax_xent: loss_sum is one float")
+    if correct is not None and (correct.dtype != torch.int32 or correct.numel() != 1 or not correct.is_cuda):
+        raise HipKernelError("softmax_xent: correct is one int32 on the GPU")
+    if row_loss is not None and _f32c(row_loss, "row_loss").numel() != M:
+        raise HipKernelError("softmax_xent: row_loss has one element per row")
+    _check(lib.dtf_softmax_xent(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(loss_sum),
+                                _ptr(correct), _ptr(row_loss), _stream()), "dtf_softmax_xent")
 
 
 def sgd_apply_(p, g, lr: torch.Tensor, scale: float = 1.0, zero_grad: bool = False,

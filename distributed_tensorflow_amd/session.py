@@ -35,6 +35,7 @@ from . import graph as G
 from .cluster import ConfigProto, lookup_server
 from .utils.trace import Collector, span
 from .models.mlp import MLPEngine
+from .ops import gemm as gemm_op
 from .optim import Optimizer, SyncReplicasOptimizer
 from .parallel.store import LocalVariableStore, RemoteVariableStore
 from .placement import DeviceSpec
@@ -73,24 +74,10 @@ def _linear(node):
 def match_mlp(loss) -> Optional[Dict[str, Any]]:
     """Recognise  mean(-sum(y_ * log(softmax(act(x W1 + b1) W2 + b2)), 1))  (tfdist_between.py:55-62)
     or mean(softmax_cross_entropy_with_logits(labels=y_, logits=...))."""
-    if not _is(loss, "reduce_mean"):
+    head = _match_head(loss)
+    if head is None:
         return None
-    inner = loss.inputs[0]
-    y_ = probs = logits = None
-    if _is(inner, "softmax_xent"):
-        y_, logits = inner.inputs
-    elif _is(inner, "neg") and _is(inner.inputs[0], "reduce_sum") and inner.inputs[0].attrs["axis"] in ((1,), (-1,)):
-        prod = inner.inputs[0].inputs[0]
-        if not _is(prod, "mul"):
-            return None
-        for a, b in (prod.inputs, prod.inputs[::-1]):
-            if _is(b, "log") and _is(b.inputs[0], "softmax"):
-                y_, probs = a, b.inputs[0]
-                logits = probs.inputs[0]
-        if logits is None:
-            return None
-    else:
-        return None
+    y_, probs, logits = head
     l2 = _linear(logits)
     if l2 is None:
         return None
@@ -107,6 +94,71 @@ def match_mlp(loss) -> Optional[Dict[str, Any]]:
         return None
     return {"x": x, "y_": y_, "W1": W1, "b1": b1, "W2": W2, "b2": b2, "act": a2.op, "logits": logits,
             "probs": probs, "loss": loss, "hidden": a2}
+
+
+def _match_head(loss):
+    """(y_, probs or None, logits) of  mean(-sum(y_ * log(softmax(logits)), 1))  or
+    mean(softmax_cross_entropy_with_logits(labels=y_, logits=logits)), else None."""
+    if not _is(loss, "reduce_mean"):
+        return None
+    inner = loss.inputs[0]
+    if _is(inner, "softmax_xent"):
+        y_, logits = inner.inputs
+        return y_, None, logits
+    if _is(inner, "neg") and _is(inner.inputs[0], "reduce_sum") and inner.inputs[0].attrs["axis"] in ((1,), (-1,)):
+        prod = inner.inputs[0].inputs[0]
+        if _is(prod, "mul"):
+            for a, b in (prod.inputs, prod.inputs[::-1]):
+                if _is(b, "log") and _is(b.inputs[0], "softmax"):
+                    return a, b.inputs[0], b.inputs[0].inputs[0]
+    return None
+
+
+def _linear_or_matmul(node):
+    """add(matmul(h, W), b) -> (h, W, b);  matmul(h, W) -> (h, W, None)"""
+    lin = _linear(node)
+    if lin is not None:
+        return lin
+    if _is(node, "matmul") and not node.attrs["transpose_a"] and not node.attrs["transpose_b"] \
+            and isinstance(node.inputs[1], G.Variable):
+        return node.inputs[0], node.inputs[1], None
+    return None
+
+
+def match_dense_stack(loss) -> Optional[Dict[str, Any]]:
+    """Recognise the reference's graph with ANY number of fully connected layers: a softmax cross-entropy head
+    (either spelling, see :func:`_match_head`) over  logits = h_L W_L (+ b_L),  h_i = act_i(h_{i-1} W_i (+ b_i)),
+    h_0 = a placeholder, act_i in sigmoid / relu / tanh  (tfdist_between.py:55-62 is the two-layer case).  Served by
+    ``models.dense.DenseStackEngine``."""
+    head = _match_head(loss)
+    if head is None:
+        return None
+    y_, probs, logits = head
+    layers, acts, node = [], [], logits
+    while True:
+        lin = _linear_or_matmul(node)
+        if lin is None:
+            return None
+        h, W, b = lin
+        if len(W.shape) != 2 or (b is not None and len(b.shape) != 1):
+            return None
+        layers.append((W, b))
+        if _is(h, "placeholder"):
+            x = h
+            break
+        if not isinstance(h, G.Tensor) or h.op not in ("sigmoid", "relu", "tanh"):
+            return None
+        acts.append(h.op)
+        node = h.inputs[0]
+    if not _is(y_, "placeholder"):
+        return None
+    layers.reverse()
+    acts.reverse()
+    variables = [v for W, b in layers for v in ((W, b) if b is not None else (W,))]
+    if len(set(variables)) != len(variables):
+        return None         # shared weights: the in-place update of one layer would change another
+    return {"x": x, "y_": y_, "layers": layers, "acts": acts, "logits": logits, "probs": probs, "loss": loss,
+            "variables": variables}
 
 
 def match_accuracy(node, m) -> bool:
@@ -151,6 +203,7 @@ class Session:
         self.fused_steps = 0
         self._local_step_ready = False
         self.generic_steps = 0
+        self.dense_steps = 0        # steps of fully connected stacks other than the reference's (models/dense.py)
         # host mirror of global_step for a local session (None: unknown, re-read from the device): saves one
         # blocking device-to-host copy per sess.run that fetches it next to a train op
         self._gs_mirror: Optional[int] = None
@@ -359,12 +412,9 @@ class Session:
         elif op == "ones":
             r = torch.ones(node.attrs["shape"], device=self.device)
         elif op == "matmul":
-            a, b = ev(ins[0]), ev(ins[1])
-            if node.attrs["transpose_a"]:
-                a = a.t()
-            if node.attrs["transpose_b"]:
-                b = b.t()
-            r = a @ b
+            # the hand-written fp32 MFMA GEMM (forward and, through autograd, both gradient products) on a GPU;
+            # torch.matmul for what it does not cover
+            r = gemm_op.matmul(ev(ins[0]), ev(ins[1]), node.attrs["transpose_a"], node.attrs["transpose_b"])
         elif op == "add":
             r = ev(ins[0]) + ev(ins[1])
         elif op == "sub":
@@ -489,6 +539,31 @@ class Session:
             self._engines[key] = eng
         return eng
 
+    @staticmethod
+    def _as_f32(v) -> torch.Tensor:
+        if isinstance(v, torch.Tensor):
+            return v.to(torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+
+    def _dense_engine_for(self, d, batch: int):
+        """The engine of a matched fully connected stack (see :func:`match_dense_stack`) for one batch size: parameters
+        and gradients are views of the session's slabs, the fed batch lands in a staging pair it reads as batch 0."""
+        from .models.dense import DenseStackEngine
+
+        key = ("dense", id(d["loss"]), batch)
+        eng = self._engines.get(key)
+        if eng is None:
+            view = lambda slab, v: None if v is None else self.layout.view(slab, v.op_name)  # noqa: E731
+            weights = [view(self.theta, W) for W, _ in d["layers"]]
+            biases = [view(self.theta, b) for _, b in d["layers"]]
+            grads = [(view(self.grad, W), view(self.grad, b)) for W, b in d["layers"]]
+            eng = DenseStackEngine(weights, biases, d["acts"], batch=batch, lr=0.0, grads=grads, hist_cap=1)
+            eng._x_stage = torch.zeros((batch, eng.dims[0]), dtype=torch.float32, device=self.device)
+            eng._y_stage = torch.zeros((batch, eng.dims[-1]), dtype=torch.float32, device=self.device)
+            eng.bind_data(eng._x_stage, eng._y_stage, batches_per_epoch=1)
+            self._engines[key] = eng
+        return eng
+
     def _stage(self, eng: MLPEngine, m, feed):
         x, y = feed.get(m["x"]), feed.get(m["y_"])
         if x is None or y is None:
@@ -512,8 +587,14 @@ class Session:
                 wanted = {m[r] for r in ("W1", "b1", "W2", "b2")}
                 if set(train_op.attrs["var_list"]) != wanted:
                     m = None   # custom var_list: take the generic path
-            acc_nodes = [n for n in self.graph.nodes if m is not None and match_accuracy(n, m)]
-            plan = {"mlp": m, "acc_nodes": acc_nodes}
+            dense = None
+            if m is None and loss is not None and os.environ.get("DTF_DENSE_ENGINE", "1") != "0":
+                dense = match_dense_stack(loss)
+                if dense is not None and set(train_op.attrs["var_list"]) != set(dense["variables"]):
+                    dense = None
+            head = m if m is not None else dense
+            acc_nodes = [n for n in self.graph.nodes if head is not None and match_accuracy(n, head)]
+            plan = {"mlp": m, "dense": dense, "acc_nodes": acc_nodes}
             self._plans[id(train_op)] = plan
         return plan
 
@@ -549,6 +630,30 @@ class Session:
             for n in plan["acc_nodes"]:
                 cache[n] = cache[("acc", id(m["loss"]))]
             self.fused_steps += 1
+        elif plan.get("dense") is not None and plan["dense"]["x"] in feed and plan["dense"]["y_"] in feed:
+            d = plan["dense"]
+            eng = self._dense_engine_for(d, int(feed[d["x"]].shape[0]))
+            with span("stage"):
+                eng._x_stage.copy_(self._as_f32(feed[d["x"]]), non_blocking=True)
+                eng._y_stage.copy_(self._as_f32(feed[d["y_"]]), non_blocking=True)
+            with span("step"):
+                if not self.store.is_remote:
+                    gs_var = train_op.attrs["global_step"]
+                    eng.set_lr(lr) if getattr(eng, "_lr_val", None) != lr else None
+                    eng._lr_val = lr
+                    eng.global_step = None if gs_var is None else self._var_view(gs_var).view(1)
+                    eng.step_fused(0)
+                    applied = True
+                else:
+                    eng.step_grad(0, 1.0)
+            with span("fetch_stats"):
+                host = torch.stack((eng.loss_sum[0], eng.correct[0].to(torch.float32))).cpu() / float(eng.B)
+            cache[d["loss"]] = host[0]
+            cache[("acc", id(d["loss"]))] = host[1]
+            for n in plan["acc_nodes"]:
+                cache[n] = host[1]
+            self.fused_steps += 1
+            self.dense_steps += 1
         else:
             self.grad.zero_()
             var_list = train_op.attrs["var_list"]
@@ -632,9 +737,9 @@ class Session:
     def _try_fused_eval(self, f, feed, cache):
         """Loss / accuracy of the matched model over a fed batch, on the fused forward kernels."""
         for plan in list(self._plans.values()):
-            if not isinstance(plan, dict) or plan.get("mlp") is None:
+            if not isinstance(plan, dict) or (plan.get("mlp") is None and plan.get("dense") is None):
                 continue
-            m = plan["mlp"]
+            m = plan["mlp"] if plan.get("mlp") is not None else plan["dense"]
             is_loss = f is m["loss"]
             is_acc = (not is_loss) and match_accuracy(f, m)
             if not (is_loss or is_acc):
@@ -649,7 +754,7 @@ class Session:
                 return None
             x = torch.as_tensor(np.ascontiguousarray(feed[m["x"]], dtype=np.float32)).to(self.device)
             y = torch.as_tensor(np.ascontiguousarray(feed[m["y_"]], dtype=np.float32)).to(self.device)
-            eng = self._engine_for(m, 1)
+            eng = self._engine_for(m, 1) if plan.get("mlp") is not None else self._dense_engine_for(m, 1)
             loss, acc = eng.evaluate(x, y)
             cache[m["loss"]] = torch.tensor(loss)
             cache[("acc", id(m["loss"]))] = torch.tensor(acc)

@@ -1,0 +1,120 @@
+"""DenseStackEngine on the GPU kernels against the fp64 autograd oracle; session integration on a GPU session."""
+import numpy as np
+import pytest
+import torch
+
+import distributed_tensorflow_amd as tf
+from distributed_tensorflow_amd.models import DenseStackEngine
+
+from test_dense_stack import _batch, _oracle_step, build_deep
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stack(dims, seed=3, scale=0.5):
+    gen = torch.Generator().manual_seed(seed)
+    Ws = [torch.randn(dims[i], dims[i + 1], generator=gen) * scale / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], generator=gen) * 0.1 for i in range(len(dims) - 1)]
+    return Ws, bs, gen
+
+
+@pytest.mark.parametrize("dims,acts,B", [((784, 100, 10), ("sigmoid",), 100),
+                                         ((784, 300, 200, 10), ("relu", "sigmoid"), 100),
+                                         ((50, 33, 17, 9, 3), ("tanh", "linear", "relu"), 7),
+                                         ((64, 1000), (), 33)])
+def test_fused_steps_match_autograd(dims, acts, B):
+    Ws, bs, gen = _stack(dims)
+    nb = 3
+    x = torch.rand(nb * B, dims[0], generator=gen)
+    y = torch.eye(dims[-1])[torch.randint(0, dims[-1], (nb * B,), generator=gen)]
+    gs = torch.zeros(1, device=DEV)
+    eng = DenseStackEngine([w.to(DEV) for w in Ws], [b.to(DEV) for b in bs], acts, batch=B, lr=0.5, global_step=gs)
+    eng.bind_data(x.to(DEV), y.to(DEV))
+    for step in range(5):
+        eng.run_chunk(1, use_graph=False)
+        sl = slice((step % nb) * B, (step % nb + 1) * B)
+        want = _oracle_step(Ws, bs, acts, x[sl], y[sl], 0.5)
+        got = eng.last_stats()
+        assert abs(got[0] - want[0]) < 2e-4 * max(1.0, abs(want[0])) and abs(got[1] - want[1]) < 1e-6, (step, got, want)
+    for w, we in zip(Ws, eng.W):
+        torch.testing.assert_close(we.cpu(), w, rtol=2e-4, atol=2e-5)
+    for b, be in zip(bs, eng.b):
+        torch.testing.assert_close(be.cpu(), b, rtol=2e-4, atol=2e-5)
+    assert float(gs) == 5.0
+    loss, acc = eng.evaluate(x.to(DEV), y.to(DEV))
+    h = x.double()
+    fns = {"sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh, "linear": lambda z: z}
+    for i in range(len(Ws)):
+        z = h @ Ws[i].double() + bs[i].double()
+        h = fns[acts[i]](z) if i < len(Ws) - 1 else z
+    want_loss = float(-(y.double() * torch.log_softmax(h, 1)).sum(1).mean())
+    assert abs(loss - want_loss) < 2e-4 * max(1.0, want_loss)
+    assert abs(acc - float((h.argmax(1) == y.argmax(1)).double().mean())) < 2.0 / x.shape[0]
+
+
+def test_graph_chunks_equal_eager_steps():
+    dims, acts, B = (784, 256, 128, 10), ("relu", "relu"), 100
+    Ws, bs, gen = _stack(dims)
+    x = torch.rand(6 * B, dims[0], generator=gen).to(DEV)
+    y = torch.eye(10)[torch.randint(0, 10, (6 * B,), generator=gen)].to(DEV)
+    engines = []
+    for use_graph in (False, True):
+        eng = DenseStackEngine([w.to(DEV) for w in Ws], [b.to(DEV) for b in bs], acts, batch=B, lr=0.1,
+                               global_step=torch.zeros(1, device=DEV))
+        eng.bind_data(x, y)
+        for n in (4, 4, 4):             # 12 steps over a 6-batch epoch
+            eng.run_chunk(n, use_graph=use_graph)
+        engines.append(eng)
+    torch.cuda.synchronize()
+    a, b = engines
+    for wa, wb in zip(a.W + a.b, b.W + b.b):
+        assert torch.equal(wa, wb)
+    assert float(a.global_step) == float(b.global_step) == 12.0
+    la, lb = a.history(6, 6), b.history(6, 6)
+    # (the step's loss is a sum of per-workgroup atomics: equal up to the order of 25 additions)
+    torch.testing.assert_close(la[0], lb[0], rtol=1e-6, atol=0)
+    assert torch.equal(la[1], lb[1])
+    assert set(b._graphs) == {(0, 4), (4, 4), (2, 4)}      # (4, 4) wraps around the end of the epoch
+
+
+def test_step_grad_matches_autograd_scaled():
+    dims, acts, B = (100, 64, 10), ("sigmoid",), 50
+    Ws, bs, gen = _stack(dims)
+    x = torch.rand(B, dims[0], generator=gen)
+    y = torch.eye(10)[torch.randint(0, 10, (B,), generator=gen)]
+    grads = [(torch.zeros_like(w, device=DEV), torch.zeros_like(b, device=DEV)) for w, b in zip(Ws, bs)]
+    eng = DenseStackEngine([w.to(DEV) for w in Ws], [b.to(DEV) for b in bs], acts, batch=B, lr=0.0, grads=grads)
+    eng.bind_data(x.to(DEV), y.to(DEV))
+    eng.step_grad(0, scale=0.25)
+    W2, b2 = [w.clone() for w in Ws], [b.clone() for b in bs]
+    _oracle_step(W2, b2, acts, x, y, 1.0)
+    for (gw, gb), w, w2, b, bb in zip(grads, Ws, W2, bs, b2):
+        torch.testing.assert_close(gw.cpu(), 0.25 * (w - w2), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(gb.cpu(), 0.25 * (b - bb), rtol=1e-4, atol=1e-6)
+    for w, we in zip(Ws, eng.W):
+        assert torch.equal(we.cpu(), w)         # parameters untouched
+
+
+def test_session_on_gpu_runs_deep_graph_on_the_kernels(monkeypatch):
+    x, y = _batch(0, n=100, dims=(784, 128, 64, 10))
+
+    def run(n):
+        with tf.Graph().as_default():
+            with tf.device("/gpu:0"):
+                m = build_deep(0.05, dims=(784, 128, 64, 10), acts=("sigmoid", "relu"))
+            with tf.Session() as sess:
+                assert sess.device.type == "cuda"
+                sess.run(m.init_op)
+                out = [sess.run([m.train_op, m.loss, m.accuracy], feed_dict={m.x: x, m.y_: y})[1:] for _ in range(n)]
+                ev = sess.run([m.loss, m.accuracy], feed_dict={m.x: x, m.y_: y})
+                return out, ev, (sess.dense_steps, sess.generic_steps)
+
+    out_d, ev_d, counts_d = run(5)
+    assert counts_d == (5, 0)
+    monkeypatch.setenv("DTF_DENSE_ENGINE", "0")         # op-by-op: MatMul nodes on the same GEMM through autograd
+    out_g, ev_g, counts_g = run(5)
+    assert counts_g == (0, 5)
+    np.testing.assert_allclose(np.array(out_d, dtype=np.float64), np.array(out_g, dtype=np.float64), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(ev_d, ev_g, rtol=2e-4, atol=1e-5)
+    assert out_d[-1][0] < out_d[0][0]
