@@ -55,84 +55,104 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// What one thread moves per chunk for one operand: NS = R / 32 slots of four k each.  With the 64-tile, chunks that lie
-// inside K take loads without clamps and tiles that lie inside the operand take LDS stores without masks (both
-// wave-uniform tests); with the 128-tile the second copy of the staging code costs more registers than the kernel has
-// (measured: 16 - 42 spilled registers, 108 -> 86 TFLOP/s), so there every chunk takes the clamped form.
+// What one thread moves per chunk for one operand: NS = R / 32 slots of four k each.
+//
+// Slot j of a thread, by layout of the operand in memory:
+//   k along memory (KC)   row 8 (wave + 4 j) + (lane & 7), k-quad lane >> 3      (8 rows x 128 bytes per instruction)
+//   k strided             row or column tid % R, k-quad tid / R + (256 / R) j    (256-byte row segments)
+// Every load is a buffer load: the descriptor points at the tile (KC) or at the tile's rows of the chunk (strided), the
+// per-lane part of the address is a 32-bit byte offset computed ONCE (rows and columns past the edge of the operand
+// clamped to its last one), and what changes per chunk, slot and k is a scalar offset - no vector arithmetic per load.
+// (Forming 64-bit addresses per load instead cost ~280 vector instructions per chunk and wave against ~80, which the
+// matrix pipe does not hide: 103 -> 118 TFLOP/s at 4096^3 NN.)  Only in the last chunk of a K that is not a multiple of
+// 32 are lanes whose k lies past the end redirected to the chunk's first k; rows, columns and k past the edge are zeroed
+// on their way to LDS.
 template <int R, bool KC, bool VEC>
 struct Stager {
   static constexpr int NS = R / 32;
-  static constexpr bool kFast = R <= 64;
-  const float* p[NS];      // address of (row or column of the slot, k = 4 kq)
-  int lds[NS], kq[NS];
-  bool ok[NS];
-  f32x4 v[NS];
+  static constexpr int NV = KC ? NS : 1;                    // distinct per-lane offsets
+  static constexpr int kQStep = KC ? 0 : kThreads / R;      // k-quads between the slots of a thread (strided form)
+  static constexpr int kLdsStep = KC ? 32 * 4 : kQStep * R * 4;
+  const float* origin;     // first element of the tile: (row r0, k 0) or (k 0, column r0)
   long ld;
   int K;
+  int wave, lane, tid;
+  unsigned voff[NV];       // bytes from the descriptor's base: the per-lane part of every address
+  bool ok[NV];             // the slot's row / column lies inside the operand
+  int lds0;                // floats: LDS offset of slot 0 (slot j: + kLdsStep * j)
   bool interior;
+  f32x4 v[NS];
 
-  __device__ __forceinline__ void init(const float* base, long ld_, int rows, int r0, int K_, int tid) {
+  __device__ __forceinline__ static __amdgpu_buffer_rsrc_t descriptor(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)0xffffffffu, 0x00020000);
+  }
+  __device__ __forceinline__ void init(const float* base, long ld_, int rows, int r0, int K_, int tid_) {
     ld = ld_;
     K = K_;
+    tid = tid_;
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     interior = r0 + R <= rows;
-    const int wave = tid >> 6, lane = tid & 63;
+    origin = KC ? base + (long)r0 * ld : base + r0;
+    if (KC) {
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      int r;
-      if (KC) {          // 8 rows x 8 k-quads per wave-instruction
-        r = 8 * (wave + 4 * j) + (lane & 7);
-        kq[j] = lane >> 3;
-      } else {           // consecutive lanes walk the rows / columns of one k-quad
-        const int slot = tid + kThreads * j;
-        r = slot % R;
-        kq[j] = slot / R;
+      for (int j = 0; j < NV; ++j) {
+        const int r = 8 * (wave + 4 * j) + (lane & 7);
+        ok[j] = r0 + r < rows;
+        voff[j] = (unsigned)(((long)(ok[j] ? r : rows - 1 - r0) * ld + 4 * (lane >> 3)) * 4);
       }
-      ok[j] = r0 + r < rows;
-      const long rr = ok[j] ? r0 + r : rows - 1;
-      p[j] = KC ? base + rr * ld + 4 * kq[j] : base + rr + (long)(4 * kq[j]) * ld;
-      lds[j] = (kq[j] * R + r) * 4;
+      lds0 = ((lane >> 3) * R + 8 * wave + (lane & 7)) * 4;
+    } else {
+      const int c = tid % R;
+      ok[0] = r0 + c < rows;
+      voff[0] = (unsigned)((ok[0] ? c : rows - 1 - r0) * 4);
+      lds0 = ((tid / R) * R + c) * 4;
     }
   }
   __device__ __forceinline__ void issue(int k0) {
-    if (kFast && k0 + kChunk <= K) {
+    const bool full = k0 + kChunk <= K;
+    if (KC) {
+      const __amdgpu_buffer_rsrc_t rsrc = descriptor(origin);
+      const int kl = 4 * (lane >> 3);                 // this lane's first k inside the chunk
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        if (KC && VEC) {
-          v[j] = *reinterpret_cast<const f32x4*>(p[j] + k0);
-        } else {
-          const float* b = KC ? p[j] + k0 : p[j] + (long)k0 * ld;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) v[j][s] = KC ? b[s] : b[s * ld];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        const int k = k0 + 4 * kq[j];
-        if (KC && VEC) {          // (K is a multiple of 4 here: a quad is inside or outside as a whole)
-          v[j] = *reinterpret_cast<const f32x4*>(p[j] + (k < K ? (long)k0 : -(long)(4 * kq[j])));
+        if (VEC) {        // K is a multiple of 4: a quad is inside or outside as a whole
+          const unsigned off = (full || k0 + kl < K) ? voff[j] : voff[j] - 4 * kl;
+          v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * 4, 0));
         } else {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const long rel = (k + s < K ? k + s : 0) - 4 * kq[j];       // k clamped, relative to p[j]
-            v[j][s] = KC ? p[j][rel] : p[j][rel * ld];
+            const unsigned off = (full || k0 + kl + s < K) ? voff[j] + 4 * s : voff[j] - 4 * kl;
+            v[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, k0 * 4, 0));
           }
         }
       }
+    } else {
+      const __amdgpu_buffer_rsrc_t rsrc = descriptor(origin + (long)k0 * ld);      // the chunk's first row
+      const int kq_w = __builtin_amdgcn_readfirstlane(tid / R);                    // uniform within a wave
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          int kk = 4 * (kq_w + kQStep * j) + s;
+          kk = (full || k0 + kk < K) ? kk : 0;
+          v[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[0], (int)(kk * ld * 4), 0));
+        }
     }
   }
   __device__ __forceinline__ void write(int k0, float* img) const {
-    if (kFast && interior && k0 + kChunk <= K) {
+    if (interior && k0 + kChunk <= K) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds[j]) = v[j];
+      for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = v[j];
     } else {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        const int k = k0 + 4 * kq[j];
+        const int k = k0 + 4 * (KC ? lane >> 3 : tid / R + kQStep * j);
+        const bool row_ok = ok[KC ? j : 0];
         f32x4 o = v[j];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) o[s] = (ok[j] && k + s < K) ? o[s] : 0.f;
-        *reinterpret_cast<f32x4*>(img + lds[j]) = o;
+        for (int s = 0; s < 4; ++s) o[s] = (row_ok && k + s < K) ? o[s] : 0.f;
+        *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = o;
       }
     }
   }
@@ -391,6 +411,8 @@ extern "C" int dtf_gemm_f32(int layout, int epi, const float* A, const float* B,
   if (epi == DTF_EPI_ACT_BWD && (aux == nullptr || ldaux < N)) return DTF_ERR_NULL;
   if (epi == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
   if (tile != 0 && tile != 64 && tile != 128) return DTF_ERR_SHAPE;
+  // byte offsets inside a tile (k along memory: 128 rows; k strided: the 32 rows of a chunk) are 32-bit
+  if ((128 * lda + K) * 4 >= (1LL << 31) || (128 * ldb + K) * 4 >= (1LL << 31)) return DTF_ERR_UNSUPPORTED;
   GemmArgs a{};
   a.A = A; a.B = B; a.C = C;
   a.M = M; a.N = N; a.K = K;
