@@ -33,6 +33,12 @@
 #include "dtf_common.h"
 #include "dtf_internal.h"
 
+#include <type_traits>
+
+#ifndef DTF_GEMM_DEPTH64
+#define DTF_GEMM_DEPTH64 1
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -67,7 +73,7 @@ struct GemmArgs {
 // matrix pipe does not hide: 103 -> 118 TFLOP/s at 4096^3 NN.)  Only in the last chunk of a K that is not a multiple of
 // 32 are lanes whose k lies past the end redirected to the chunk's first k; rows, columns and k past the edge are zeroed
 // on their way to LDS.
-template <int R, bool KC, bool VEC>
+template <int R, bool KC, bool VEC, int D>
 struct Stager {
   static constexpr int NS = R / 32;
   static constexpr int NV = KC ? NS : 1;                    // distinct per-lane offsets
@@ -81,7 +87,7 @@ struct Stager {
   bool ok[NV];             // the slot's row / column lies inside the operand
   int lds0;                // floats: LDS offset of slot 0 (slot j: + kLdsStep * j)
   bool interior;
-  f32x4 v[NS];
+  f32x4 v[D][NS];          // D chunks in flight between memory and LDS
 
   __device__ __forceinline__ static __amdgpu_buffer_rsrc_t descriptor(const float* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)0xffffffffu, 0x00020000);
@@ -109,6 +115,7 @@ struct Stager {
       lds0 = ((tid / R) * R + c) * 4;
     }
   }
+  template <int S>
   __device__ __forceinline__ void issue(int k0) {
     const bool full = k0 + kChunk <= K;
     if (KC) {
@@ -118,12 +125,12 @@ struct Stager {
       for (int j = 0; j < NS; ++j) {
         if (VEC) {        // K is a multiple of 4: a quad is inside or outside as a whole
           const unsigned off = (full || k0 + kl < K) ? voff[j] : voff[j] - 4 * kl;
-          v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * 4, 0));
+          v[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * 4, 0));
         } else {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const unsigned off = (full || k0 + kl + s < K) ? voff[j] + 4 * s : voff[j] - 4 * kl;
-            v[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, k0 * 4, 0));
+            v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, k0 * 4, 0));
           }
         }
       }
@@ -136,20 +143,21 @@ struct Stager {
         for (int s = 0; s < 4; ++s) {
           int kk = 4 * (kq_w + kQStep * j) + s;
           kk = (full || k0 + kk < K) ? kk : 0;
-          v[j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[0], (int)(kk * ld * 4), 0));
+          v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[0], (int)(kk * ld * 4), 0));
         }
     }
   }
+  template <int S>
   __device__ __forceinline__ void write(int k0, float* img) const {
     if (interior && k0 + kChunk <= K) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = v[j];
+      for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = v[S][j];
     } else {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         const int k = k0 + 4 * (KC ? lane >> 3 : tid / R + kQStep * j);
         const bool row_ok = ok[KC ? j : 0];
-        f32x4 o = v[j];
+        f32x4 o = v[S][j];
 #pragma unroll
         for (int s = 0; s < 4; ++s) o[s] = (row_ok && k + s < K) ? o[s] : 0.f;
         *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = o;
@@ -183,8 +191,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
   const int i16 = lane & 15, q = lane >> 4;
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
-  Stager<BM, AK, VEC> sa;
-  Stager<BN, BK, VEC> sb;
+  // Chunks in flight between memory and LDS.  Two or three for the small tile (-DDTF_GEMM_DEPTH64=2|3) measured the
+  // same as one (100 x 784 x 1024: 37 us with each): a chunk of the small tile is not waiting for memory.
+  constexpr int D = BM <= 64 ? DTF_GEMM_DEPTH64 : 1;
+  Stager<BM, AK, VEC, D> sa;
+  Stager<BN, BK, VEC, D> sb;
   sa.init(a.A, a.lda, a.M, m0, a.K, tid);
   sb.init(a.B, a.ldb, a.N, n0, a.K, tid);
 
@@ -221,17 +232,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
   //   c+1's macro-step 0 requested from LDS | the last quarter of macro-step 1.
   // Image (c+1) & 1 is written while everybody reads image c & 1, and read only after the barrier that follows the
   // writes; its previous contents (chunk c-1) were last read before the barrier of chunk c-1.
-  sa.issue(0);
-  sb.issue(0);
-  sa.write(0, As);
-  sb.write(0, Bs);
-  if (nchunks > 1) {
-    sa.issue(kChunk);
-    sb.issue(kChunk);
-  }
-  __syncthreads();
-  read_ops(As, Bs, 0, av[0], bv[0]);
-  for (int c = 0; c < nchunks; ++c) {
+  // Loads of chunk t land in register set t % D; chunk c writes chunk c+1 to LDS and requests chunk c+1+D into the set
+  // that this frees.
+  auto chunk = [&](int c, auto parity) {
+    constexpr int S = (decltype(parity)::value + 1) % D;          // register set of chunk c+1
     const float* Ac = As + (c & 1) * kAs;
     const float* Bc = Bs + (c & 1) * kBs;
     float* An = As + ((c + 1) & 1) * kAs;
@@ -240,17 +244,40 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
     read_ops(Ac, Bc, 1, av[1], bv[1]);
     multiply(av[0], bv[0], 0, 4);
     if (more) {
-      sa.write((c + 1) * kChunk, An);
-      sb.write((c + 1) * kChunk, Bn);
-      if (c + 2 < nchunks) {
-        sa.issue((c + 2) * kChunk);
-        sb.issue((c + 2) * kChunk);
+      sa.template write<S>((c + 1) * kChunk, An);
+      sb.template write<S>((c + 1) * kChunk, Bn);
+      if (c + 1 + D < nchunks) {
+        sa.template issue<S>((c + 1 + D) * kChunk);
+        sb.template issue<S>((c + 1 + D) * kChunk);
       }
     }
     multiply(av[1], bv[1], 0, 3);
     __syncthreads();
     if (more) read_ops(An, Bn, 0, av[0], bv[0]);
     multiply(av[1], bv[1], 3, 4);
+  };
+  sa.template issue<0>(0);
+  sb.template issue<0>(0);
+  sa.template write<0>(0, As);
+  sb.template write<0>(0, Bs);
+  if (nchunks > 1) {
+    sa.template issue<1 % D>(kChunk);
+    sb.template issue<1 % D>(kChunk);
+  }
+  if (D > 1 && nchunks > 2) {
+    sa.template issue<2 % D>(2 * kChunk);
+    sb.template issue<2 % D>(2 * kChunk);
+  }
+  if (D > 2 && nchunks > 3) {
+    sa.template issue<3 % D>(3 * kChunk);
+    sb.template issue<3 % D>(3 * kChunk);
+  }
+  __syncthreads();
+  read_ops(As, Bs, 0, av[0], bv[0]);
+  for (int c = 0; c < nchunks; c += D) {
+    chunk(c, std::integral_constant<int, 0>{});
+    if (D > 1 && c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1 % D>{});
+    if (D > 2 && c + 2 < nchunks) chunk(c + 2, std::integral_constant<int, 2 % D>{});
   }
 
   // ---- epilogue: register r of block (bi, bj) is C[m0 + wm0 + 16 bi + 4 q + r][n0 + wn0 + 16 bj + i16] ----
