@@ -43,7 +43,9 @@ def define_hparam_flags():
     f.DEFINE_integer("train_size", 55000, "rows of the training split (synthetic data only)")
     f.DEFINE_string("logdir", "", "checkpoint directory (empty: no checkpoints, like the reference)")
     f.DEFINE_float("save_model_secs", 600, "checkpoint period of the chief")
-    f.DEFINE_string("activation", "sigmoid", "hidden activation: sigmoid (reference) or relu")
+    f.DEFINE_string("activation", "sigmoid", "hidden activation: sigmoid (reference), relu or tanh")
+    f.DEFINE_string("hidden", "100", "widths of the hidden layers, comma-separated: 100 is the reference's network, "
+                                     "e.g. 512,256 a deeper stack on the dense-layer kernels")
     f.DEFINE_boolean("resident", False, "device-resident hipGraph loop instead of one sess.run per batch")
     f.DEFINE_boolean("summaries", True, "write cost/accuracy summaries every step")
     f.DEFINE_integer("max_steps", 0, "stop after this many batches in total (0: run all epochs)")
@@ -56,20 +58,29 @@ def load_data(flags):
     return read_data_sets(flags.data_dir, one_hot=True, sizes=sizes)
 
 
-def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0):
-    """The reference graph; call inside the ``tf.device(...)`` scope that places it."""
+def hidden_widths(flags) -> tuple:
+    return tuple(int(v) for v in str(getattr(flags, "hidden", "100")).split(",") if v.strip())
+
+
+def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0, hidden=(100,)):
+    """The reference graph; call inside the ``tf.device(...)`` scope that places it.  ``hidden``: widths of the hidden
+    layers — (100,) is the reference's network (tfdist_between.py:48-59), more entries give the same graph with more
+    fully connected layers (variables still created weights first, then biases, as the reference does)."""
+    hidden = tuple(int(h) for h in hidden)
+    if len(hidden) != 1:
+        return _build_deep_model(lr, activation, sync_replicas, hidden)
     global_step = tf.get_variable("global_step", [], initializer=tf.constant_initializer(0), trainable=False)
     with tf.name_scope("input"):
         x = tf.placeholder(tf.float32, shape=[None, 784], name="x-input")
         y_ = tf.placeholder(tf.float32, shape=[None, 10], name="y-input")
     tf.set_random_seed(1)
     with tf.name_scope("weights"):
-        W1 = tf.Variable(tf.random_normal([784, 100]))
-        W2 = tf.Variable(tf.random_normal([100, 10]))
+        W1 = tf.Variable(tf.random_normal([784, hidden[0]]))
+        W2 = tf.Variable(tf.random_normal([hidden[0], 10]))
     with tf.name_scope("biases"):
-        b1 = tf.Variable(tf.zeros([100]))
+        b1 = tf.Variable(tf.zeros([hidden[0]]))
         b2 = tf.Variable(tf.zeros([10]))
-    act = tf.nn.relu if activation == "relu" else tf.nn.sigmoid
+    act = {"relu": tf.nn.relu, "tanh": tf.nn.tanh}.get(activation, tf.nn.sigmoid)
     with tf.name_scope("softmax"):
         a2 = act(tf.add(tf.matmul(x, W1), b1))
         y = tf.nn.softmax(tf.add(tf.matmul(a2, W2), b2))
@@ -90,6 +101,48 @@ def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0):
     tf.summary.scalar("cost", cross_entropy)
     tf.summary.scalar("accuracy", accuracy)
     return SimpleNamespace(global_step=global_step, x=x, y_=y_, W1=W1, W2=W2, b1=b1, b2=b2, y=y,
+                           cross_entropy=cross_entropy, train_op=train_op, accuracy=accuracy,
+                           summary_op=tf.summary.merge_all(), init_op=tf.global_variables_initializer(),
+                           sync_opt=sync_opt)
+
+
+def _build_deep_model(lr: float, activation: str, sync_replicas: int, hidden):
+    """The reference graph with ``len(hidden)`` hidden layers (none: softmax regression).  Weights are drawn with
+    standard deviation 1 / sqrt(fan-in): the reference's N(0, 1) saturates every unit of a second hidden layer."""
+    dims = (784,) + tuple(hidden) + (10,)
+    global_step = tf.get_variable("global_step", [], initializer=tf.constant_initializer(0), trainable=False)
+    with tf.name_scope("input"):
+        x = tf.placeholder(tf.float32, shape=[None, 784], name="x-input")
+        y_ = tf.placeholder(tf.float32, shape=[None, 10], name="y-input")
+    tf.set_random_seed(1)
+    with tf.name_scope("weights"):
+        weights = [tf.Variable(tf.random_normal([dims[i], dims[i + 1]], stddev=dims[i] ** -0.5))
+                   for i in range(len(dims) - 1)]
+    with tf.name_scope("biases"):
+        biases = [tf.Variable(tf.zeros([dims[i + 1]])) for i in range(len(dims) - 1)]
+    act = {"relu": tf.nn.relu, "tanh": tf.nn.tanh}.get(activation, tf.nn.sigmoid)
+    with tf.name_scope("softmax"):
+        h = x
+        for W, b in zip(weights[:-1], biases[:-1]):
+            h = act(tf.add(tf.matmul(h, W), b))
+        y = tf.nn.softmax(tf.add(tf.matmul(h, weights[-1]), biases[-1]))
+    with tf.name_scope("cross_entropy"):
+        cross_entropy = tf.reduce_mean(-tf.reduce_sum(y_ * tf.log(y), reduction_indices=[1]))
+    with tf.name_scope("train"):
+        opt = tf.train.GradientDescentOptimizer(lr)
+        sync_opt = None
+        if sync_replicas:
+            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=sync_replicas,
+                                                      total_num_replicas=sync_replicas, use_locking=True)
+            train_op = sync_opt.minimize(cross_entropy, global_step=global_step)
+        else:
+            train_op = opt.minimize(cross_entropy, global_step=global_step)
+    with tf.name_scope("Accuracy"):
+        correct = tf.equal(tf.argmax(y, 1), tf.argmax(y_, 1))
+        accuracy = tf.reduce_mean(tf.cast(correct, tf.float32))
+    tf.summary.scalar("cost", cross_entropy)
+    tf.summary.scalar("accuracy", accuracy)
+    return SimpleNamespace(global_step=global_step, x=x, y_=y_, weights=weights, biases=biases, y=y,
                            cross_entropy=cross_entropy, train_op=train_op, accuracy=accuracy,
                            summary_op=tf.summary.merge_all(), init_op=tf.global_variables_initializer(),
                            sync_opt=sync_opt)
@@ -219,7 +272,7 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
     n_workers = cluster.num_tasks("worker")
     with tf.device(tf.train.replica_device_setter(
             worker_device="/job:worker/task:%d/gpu:%d" % (flags.task_index, flags.task_index), cluster=cluster)):
-        m = build_model(flags.lr, flags.activation, sync_replicas=n_workers if sync else 0)
+        m = build_model(flags.lr, flags.activation, sync_replicas=n_workers if sync else 0, hidden=hidden_widths(flags))
         print("Ready to go")
     is_chief = flags.task_index == 0
     sv = tf.train.Supervisor(is_chief=is_chief, global_step=m.global_step, init_op=m.init_op,
@@ -230,7 +283,11 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
         if sync and is_chief:
             sv.start_queue_runners(sess, [chief_queue_runner])
         writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
-        if flags.resident and sync:
+        if flags.resident and hidden_widths(flags) != (100,):
+            print("--resident against parameter servers is built for the reference's 784-100-10 network; "
+                  "this stack runs one sess.run per batch on the dense-layer kernels", flush=True)
+            result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
+        elif flags.resident and sync:
             from ..data import DeviceDataset
             from ..parallel.ps_resident import PsSyncResidentTrainer
 

@@ -61,7 +61,7 @@ def _oracle_step(Ws, bs, acts, x, y, lr):
             w.copy_((wd - lr * wd.grad).float())
         for b, b_d in zip(bs, bd):
             b.copy_((b_d - lr * b_d.grad).float())
-    return float(loss), float(acc)
+    return float(loss.detach()), float(acc)
 
 
 def test_matcher_accepts_deep_stacks_and_rejects_others():
@@ -189,3 +189,55 @@ def test_deep_graph_against_parameter_servers_async():
     finally:
         for s in servers + [worker]:
             s.stop()
+
+
+def test_resident_trainer_steps_the_sessions_variables():
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+    from distributed_tensorflow_amd.parallel.dense_trainer import DenseResidentTrainer
+
+    rng = np.random.RandomState(0)
+    protos = rng.rand(10, 784).astype(np.float32)
+    labels = rng.randint(0, 10, 600)
+    images = (protos[labels] + 0.3 * rng.rand(600, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    with tf.Graph().as_default():
+        m = build_model(0.05, "relu", hidden=(32, 16))
+        assert len(m.weights) == 3 and m.weights[0].shape == (784, 32)
+        with tf.Session() as sess:
+            sess.run(m.init_op)
+            w0 = sess.var_tensor(m.weights[0]).clone()
+            ds = DeviceDataset(images, onehot, sess.device, 50, seed=3)
+            tr = DenseResidentTrainer(sess, m.train_op, ds, 50, chunk=5)
+            assert "784-32-16-10" in tr.describe() and tr.engine.batches_per_epoch == 12
+            first = tr.evaluate(torch.as_tensor(images), torch.as_tensor(onehot))
+            tr.run_steps(30)                    # two and a half epochs: crosses two reshuffles
+            assert tr.global_step_value() == 30 and sess.run(m.global_step) == 30.0
+            last = tr.evaluate(torch.as_tensor(images), torch.as_tensor(onehot))
+            assert last[0] < first[0] and last[1] > first[1]
+            assert not torch.equal(sess.var_tensor(m.weights[0]), w0)           # the session's own variables moved
+            # the session evaluates the same numbers from the same variables
+            loss, acc = sess.run([m.cross_entropy, m.accuracy], feed_dict={m.x: images, m.y_: onehot})
+            assert abs(loss - last[0]) < 1e-5 and abs(acc - last[1]) < 1e-6
+            # and a step through sess.run continues from where the trainer stopped
+            _, step = sess.run([m.train_op, m.global_step], feed_dict={m.x: images[:50], m.y_: onehot[:50]})
+            assert step == 30.0 and sess.dense_steps == 1
+            tr.close()
+
+
+def test_tfsingle_script_with_hidden_layers(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    from cluster_utils import ROOT
+
+    for extra in (["--resident"], []):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tfsingle.py"), "--hidden", "48,24", "--activation", "relu",
+                              "--lr", "0.05", "--epochs", "2", "--train_size", "2200", "--logs_path", str(tmp_path), *extra],
+                             cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300,
+                             env=dict(os.environ, PYTHONPATH=ROOT))
+        assert out.returncode == 0, out.stdout[-2000:]
+        assert "Step: 44,  Epoch:  2,  Batch:  22 of  22" in out.stdout and out.stdout.rstrip().endswith("Done")
+        accs = [float(line.split(":")[1]) for line in out.stdout.splitlines() if line.startswith("Test-Accuracy")]
+        assert len(accs) == 2 and accs[-1] > 0.5

@@ -118,3 +118,32 @@ def test_session_on_gpu_runs_deep_graph_on_the_kernels(monkeypatch):
     np.testing.assert_allclose(np.array(out_d, dtype=np.float64), np.array(out_g, dtype=np.float64), rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(ev_d, ev_g, rtol=2e-4, atol=1e-5)
     assert out_d[-1][0] < out_d[0][0]
+
+
+def test_resident_trainer_graph_replay_equals_eager_across_reshuffles():
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+    from distributed_tensorflow_amd.parallel.dense_trainer import DenseResidentTrainer
+
+    rng = np.random.RandomState(0)
+    labels = rng.randint(0, 10, 1200)
+    images = (rng.rand(10, 784).astype(np.float32)[labels] + 0.3 * rng.rand(1200, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    finals = []
+    for use_graph in (False, True):
+        with tf.Graph().as_default():
+            with tf.device("/gpu:0"):
+                m = build_model(0.05, "relu", hidden=(256, 128))
+            with tf.Session() as sess:
+                sess.run(m.init_op)
+                ds = DeviceDataset(images, onehot, sess.device, 100, seed=3)
+                tr = DenseResidentTrainer(sess, m.train_op, ds, 100, chunk=5, use_graph=use_graph)
+                tr.prepare((30,))
+                tr.run_steps(30)                # 12 batches per epoch: two reshuffles
+                assert tr.global_step_value() == 30
+                finals.append([sess.var_tensor(v).clone() for v in m.weights + m.biases] + [tr.evaluate(
+                    torch.as_tensor(images).cuda(), torch.as_tensor(onehot).cuda())])
+                tr.close()
+    for a, b in zip(finals[0][:-1], finals[1][:-1]):
+        assert torch.equal(a, b)
+    assert finals[0][-1][1] > 0.8

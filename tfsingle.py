@@ -4,6 +4,7 @@ parameter server, the model pinned to /gpu:0 with soft placement.
 
     python tfsingle.py                 # one sess.run per batch, like the reference
     python tfsingle.py --resident      # device-resident data + hipGraph replay (fast tier)
+    python tfsingle.py --resident --hidden 512,256 --activation relu --lr 0.05    # a deeper stack, dense-layer kernels
 """
 import time
 
@@ -18,7 +19,26 @@ def main(_):
     mnist = mnist_mlp.load_data(FLAGS)
     print("worker setting up ...", flush=True)
     begin_time = time.time()
-    if FLAGS.resident:
+    hidden = mnist_mlp.hidden_widths(FLAGS)
+    if FLAGS.resident and hidden != (100,):
+        # any other fully connected stack: variables in a session, steps replayed from hipGraphs of dense-layer launches
+        import torch
+
+        from distributed_tensorflow_amd.data import DeviceDataset
+        from distributed_tensorflow_amd.parallel.dense_trainer import DenseResidentTrainer
+
+        with tf.device("/gpu:0"):
+            m = mnist_mlp.build_model(FLAGS.lr, FLAGS.activation, hidden=hidden)
+            print("Ready to go")
+        with tf.Session(config=mnist_mlp.make_config(FLAGS)) as sess:
+            sess.run(m.init_op)
+            ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, FLAGS.batch_size, seed=0)
+            trainer = DenseResidentTrainer(sess, m.train_op, ds, FLAGS.batch_size, chunk=min(FLAGS.freq, 550))
+            print(trainer.describe(), flush=True)
+            writer = tf.summary.FileWriter(FLAGS.logs_path, graph=tf.get_default_graph()) if FLAGS.summaries else None
+            mnist_mlp.run_resident_loop(trainer, mnist, FLAGS, writer, begin_time)
+            trainer.close()
+    elif FLAGS.resident:
         import torch
 
         from distributed_tensorflow_amd.data import DeviceDataset
@@ -33,7 +53,7 @@ def main(_):
         mnist_mlp.run_resident_loop(trainer, mnist, FLAGS, writer, begin_time)
     else:
         with tf.device("/gpu:0"):
-            m = mnist_mlp.build_model(FLAGS.lr, FLAGS.activation)
+            m = mnist_mlp.build_model(FLAGS.lr, FLAGS.activation, hidden=hidden)
             print("Ready to go")
         with tf.Session(config=mnist_mlp.make_config(FLAGS)) as sess:
             sess.run(m.init_op)
