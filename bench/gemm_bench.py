@@ -35,8 +35,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default=DEFAULT)
     ap.add_argument("--tiles", default="0")
+    ap.add_argument("--workspace", type=int, default=1, help="1: let shapes with few tiles split K (the engines' setting)")
     a = ap.parse_args()
     dev = torch.device("cuda")
+    ws = hb.gemm_workspace(dev) if a.workspace else None
     print(f"{'M x N x K':>20} {'layout':>6} {'tile':>4} {'ours us':>10} {'TFLOP/s':>8} {'library us':>10} {'TFLOP/s':>8} {'ours/lib':>8} {'max diff':>9}")
     for shape in a.shapes.split(","):
         M, N, K = (int(v) for v in shape.split("x"))
@@ -50,7 +52,7 @@ def main():
             Bt = B.t() if layout == hb.GEMM_NT else B
             t_lib = timed(lambda: torch.matmul(At, Bt, out=lib_out), a.iters)
             for tile in (int(t) for t in a.tiles.split(",")):
-                t_ours = timed(lambda: hb.gemm(layout, A, B, out=out, tile=tile), a.iters)
+                t_ours = timed(lambda: hb.gemm(layout, A, B, out=out, tile=tile, workspace=ws), a.iters)
                 diff = float((out - lib_out).abs().max())
                 print(f"{shape:>20} {name:>6} {tile:>4} {t_ours:>10.1f} {flop / t_ours / 1e6:>8.1f} {t_lib:>10.1f} "
                       f"{flop / t_lib / 1e6:>8.1f} {t_lib / t_ours:>8.2f} {diff:>9.2e}", flush=True)

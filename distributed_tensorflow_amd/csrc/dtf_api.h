@@ -189,9 +189,18 @@ int dtf_xgmi_pull_ranges(const uint64_t* shards, const int64_t* starts, int worl
 int dtf_gemm_f32(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K, int64_t lda,
                  int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux, int64_t ldaux,
                  const float* lr, float scale, int tile, void* stream);
+// The same with a workspace (zero-filled once by the caller, then only used by these calls, one stream at a time):
+// shapes with few tiles and a long K are then computed by several workgroups per tile, the last of which adds the
+// partial sums in a fixed order and runs the epilogue.  splits: 0 = chosen from the shape, n = at most n.
+int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K, int64_t lda,
+                    int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux, int64_t ldaux,
+                    const float* lr, float scale, int tile, float* workspace, int64_t workspace_floats, int splits,
+                    void* stream);
 // out[n] = scale * sum_m z[m*ldz + n]  (mode DTF_EPI_NONE)  or  out[n] -= lr[0] * scale * sum  (mode DTF_EPI_SGD)
 int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out, int mode, float scale, const float* lr,
                void* stream);
+// Start of a training step of a dense stack: *loss_sum = 0, *correct = 0, *global_step += 1 (each may be null).
+int dtf_dense_step_begin(float* loss_sum, int32_t* correct, float* global_step, void* stream);
 // Softmax cross-entropy over logits [M][C] against (soft) labels [M][C]: loss_sum += sum of the row losses, correct +=
 // rows whose argmax matches the labels' (both accumulated, either may be null), dz = grad_scale * dLoss_row/dlogits
 // (null: forward only), row_loss[m] (may be null).

@@ -59,6 +59,9 @@ struct GemmArgs {
   const float* lr;         // DTF_EPI_SGD: device learning rate
   float scale;             // DTF_EPI_SGD: C -= lr * scale * acc;  DTF_EPI_NONE: C = scale * acc
   int tiles_m, tiles_n;
+  int splits;              // workgroups per tile, each with a range of K (1: none)
+  long ws_floats;          // size of ws
+  float* ws;               // splits > 1: [1024 tile counters, zero between launches][splits][tiles][BM * BN] partial sums
 };
 
 // What one thread moves per chunk for one operand: NS = R / 32 slots of four k each.
@@ -177,10 +180,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
 
   // ---- which tile (see "Placement") ----
   const int T = a.tiles_m * a.tiles_n;
-  int tile;
+  int tile, split;
   {
-    const int orig = blockIdx.x, xcd = orig & 7, qq = T >> 3, rr = T & 7;
-    tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int total = T * a.splits;
+    const int orig = blockIdx.x, xcd = orig & 7, qq = total >> 3, rr = total & 7;
+    const int id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    tile = id / a.splits;          // the workgroups of a tile are neighbours on one XCD
+    split = id - tile * a.splits;
   }
   const int group_sz = kGroupM * a.tiles_n, g = tile / group_sz, first_m = g * kGroupM;
   const int gm = a.tiles_m - first_m < kGroupM ? a.tiles_m - first_m : kGroupM;
@@ -206,7 +212,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
     for (int bj = 0; bj < TN; ++bj) acc[bi][bj] = zero4;
 
-  const int nchunks = (a.K + kChunk - 1) / kChunk;
+  // this workgroup's chunks of K: all of them, or range `split` of `splits` equal ranges (the launcher leaves none empty)
+  const int all_chunks = (a.K + kChunk - 1) / kChunk;
+  const int per_split = (all_chunks + a.splits - 1) / a.splits;
+  const int cbeg = split * per_split;
+  const int nchunks = all_chunks - cbeg < per_split ? all_chunks - cbeg : per_split;
   // operand registers of one macro-step: [0] = macro-step 0 of a chunk, [1] = macro-step 1
   f32x4 av[2][TM], bv[2][TN];
   auto read_ops = [&](const float* Ac, const float* Bc, int ms, f32x4 (&ar)[TM], f32x4 (&br)[TN]) {
@@ -244,11 +254,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
     read_ops(Ac, Bc, 1, av[1], bv[1]);
     multiply(av[0], bv[0], 0, 4);
     if (more) {
-      sa.template write<S>((c + 1) * kChunk, An);
-      sb.template write<S>((c + 1) * kChunk, Bn);
+      sa.template write<S>((cbeg + c + 1) * kChunk, An);
+      sb.template write<S>((cbeg + c + 1) * kChunk, Bn);
       if (c + 1 + D < nchunks) {
-        sa.template issue<S>((c + 1 + D) * kChunk);
-        sb.template issue<S>((c + 1 + D) * kChunk);
+        sa.template issue<S>((cbeg + c + 1 + D) * kChunk);
+        sb.template issue<S>((cbeg + c + 1 + D) * kChunk);
       }
     }
     multiply(av[1], bv[1], 0, 3);
@@ -256,21 +266,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
     if (more) read_ops(An, Bn, 0, av[0], bv[0]);
     multiply(av[1], bv[1], 3, 4);
   };
-  sa.template issue<0>(0);
-  sb.template issue<0>(0);
-  sa.template write<0>(0, As);
-  sb.template write<0>(0, Bs);
+  sa.template issue<0>(cbeg * kChunk);
+  sb.template issue<0>(cbeg * kChunk);
+  sa.template write<0>(cbeg * kChunk, As);
+  sb.template write<0>(cbeg * kChunk, Bs);
   if (nchunks > 1) {
-    sa.template issue<1 % D>(kChunk);
-    sb.template issue<1 % D>(kChunk);
+    sa.template issue<1 % D>((cbeg + 1) * kChunk);
+    sb.template issue<1 % D>((cbeg + 1) * kChunk);
   }
   if (D > 1 && nchunks > 2) {
-    sa.template issue<2 % D>(2 * kChunk);
-    sb.template issue<2 % D>(2 * kChunk);
+    sa.template issue<2 % D>((cbeg + 2) * kChunk);
+    sb.template issue<2 % D>((cbeg + 2) * kChunk);
   }
   if (D > 2 && nchunks > 3) {
-    sa.template issue<3 % D>(3 * kChunk);
-    sb.template issue<3 % D>(3 * kChunk);
+    sa.template issue<3 % D>((cbeg + 3) * kChunk);
+    sb.template issue<3 % D>((cbeg + 3) * kChunk);
   }
   __syncthreads();
   read_ops(As, Bs, 0, av[0], bv[0]);
@@ -278,6 +288,50 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
     chunk(c, std::integral_constant<int, 0>{});
     if (D > 1 && c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1 % D>{});
     if (D > 2 && c + 2 < nchunks) chunk(c + 2, std::integral_constant<int, 2 % D>{});
+  }
+
+  // ---- K split over several workgroups: partial sums meet in the workspace, the LAST workgroup of a tile to arrive
+  // adds them in range order (the same bits whatever the arrival order) and runs the epilogue.  Hand-off: plain stores,
+  // every wave waits for its stores, barrier, ONE agent-scope release ahead of the ticket, and ONE agent-scope acquire in
+  // the workgroup that drew the last ticket before anybody reads; the counter goes back to zero for the next launch.
+  if (a.splits > 1) {
+    constexpr int kTileFloats = BM * BN;
+    unsigned* counters = reinterpret_cast<unsigned*>(a.ws);
+    float* slabs = a.ws + 1024;
+    float* mine = slabs + ((long)split * T + tile) * kTileFloats;
+#pragma unroll
+    for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < TN; ++bj)
+        *reinterpret_cast<f32x4*>(mine + ((bi * TN + bj) * kThreads + tid) * 4) = acc[bi][bj];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last = reinterpret_cast<int*>(smem);          // (LDS is free: the K loop ended behind a barrier)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *last = ticket == (unsigned)a.splits - 1u ? 1 : 0;
+      if (*last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        counters[tile] = 0u;
+      }
+    }
+    __syncthreads();
+    if (*last == 0) return;
+#pragma unroll
+    for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < TN; ++bj) acc[bi][bj] = zero4;
+    for (int sidx = 0; sidx < a.splits; ++sidx) {
+      const float* slab = slabs + ((long)sidx * T + tile) * kTileFloats;
+#pragma unroll
+      for (int bi = 0; bi < TM; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < TN; ++bj)
+          acc[bi][bj] += *reinterpret_cast<const f32x4*>(slab + ((bi * TN + bj) * kThreads + tid) * 4);
+    }
   }
 
   // ---- epilogue: register r of block (bi, bj) is C[m0 + wm0 + 16 bi + 4 q + r][n0 + wn0 + 16 bj + i16] ----
@@ -322,7 +376,23 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs b = a;
   b.tiles_m = (a.M + BM - 1) / BM;
   b.tiles_n = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), dim3(b.tiles_m * b.tiles_n), dim3(kThreads), bytes, stream,
+  // K split: when the tiles leave most CUs idle and K is long, several workgroups share a tile (see the kernel's end).
+  // Needs the caller's workspace: 1024 counters + splits x tiles x BM x BN floats.
+  const long T = (long)b.tiles_m * b.tiles_n, chunks = (a.K + kChunk - 1) / kChunk;
+  int splits = 1;
+  if (a.ws != nullptr && T <= 128 && chunks >= 4) {
+    long want = a.splits > 0 ? a.splits : 256 / T;            // fill the chip once
+    if (want > chunks / 2) want = chunks / 2;                  // at least two chunks per workgroup
+    if (want > 16) want = 16;
+    const long room = (a.ws_floats - 1024) / (T * BM * BN);
+    if (want > room) want = room;
+    if (want >= 2) {
+      const long per = (chunks + want - 1) / want;
+      splits = (int)((chunks + per - 1) / per);                // no empty range
+    }
+  }
+  b.splits = splits;
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), dim3((unsigned)(T * splits)), dim3(kThreads), bytes, stream,
                      b);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
@@ -336,30 +406,49 @@ int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
 }
 
 // ---- column sums: out[n] (op)= scale * sum_m z[m][n] -------------------------------------------------------------
-// A workgroup owns 64 columns; its four waves walk the rows four apart (every load a 256-byte row segment) and meet in LDS.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ z, long ldz, int M, int N, float* out,
-                                                     int mode, float scale, const float* lr) {
-  __shared__ float part[4][64];
+// A workgroup owns 64 columns and a segment of up to kColsumRows rows; its 16 waves walk the rows 16 apart with four
+// loads in flight each (every load a 256-byte row segment; the 13 dependent round trips of a four-wave, two-load version
+// took 4.6 us for 100 rows) and meet in LDS.  Several segments (tall matrices) add their parts with float atomics: the
+// SGD form is a sum of decrements anyway, the plain form then needs `out` zeroed first (done by the launcher).
+constexpr int kColsumRows = 2048;
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ z, long ldz, int M, int N, float* out,
+                                                      int mode, float scale, const float* lr) {
+  __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
+  const int m_begin = blockIdx.y * kColsumRows, m_end = m_begin + kColsumRows < M ? m_begin + kColsumRows : M;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (n < N) {
-    int m = wave;
-    for (; m + 4 < M; m += 8) {
+    int m = m_begin + wave;
+    for (; m + 48 < m_end; m += 64) {
       s0 += z[(long)m * ldz + n];
-      s1 += z[(long)(m + 4) * ldz + n];
+      s1 += z[(long)(m + 16) * ldz + n];
+      s2 += z[(long)(m + 32) * ldz + n];
+      s3 += z[(long)(m + 48) * ldz + n];
     }
-    if (m < M) s0 += z[(long)m * ldz + n];
+    for (; m < m_end; m += 16) s0 += z[(long)m * ldz + n];
   }
-  part[wave][lane] = s0 + s1;
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (wave == 0 && n < N) {
-    const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    if (mode == DTF_EPI_SGD)
-      out[n] -= lr[0] * scale * s;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += part[w][lane];
+    const float v = mode == DTF_EPI_SGD ? -lr[0] * scale * s : scale * s;
+    if (gridDim.y > 1)
+      atomicAdd(out + n, v);
+    else if (mode == DTF_EPI_SGD)
+      out[n] += v;
     else
-      out[n] = scale * s;
+      out[n] = v;
   }
+}
+
+// ---- start of a training step: the step's loss / accuracy accumulators cleared, the step counter bumped (one thread) ---
+__global__ void dense_step_begin_kernel(float* loss_sum, int* correct, float* global_step) {
+  if (loss_sum != nullptr) *loss_sum = 0.f;
+  if (correct != nullptr) *correct = 0;
+  if (global_step != nullptr) *global_step += 1.0f;
 }
 
 // ---- softmax cross-entropy head over logits [M][C] -----------------------------------------------------------------
@@ -431,6 +520,14 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 extern "C" int dtf_gemm_f32(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K,
                             int64_t lda, int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux,
                             int64_t ldaux, const float* lr, float scale, int tile, void* stream) {
+  return dtf_gemm_f32_ws(layout, epi, A, B, C, M, N, K, lda, ldb, ldc, act, bias, aux, ldaux, lr, scale, tile, nullptr, 0,
+                         0, stream);
+}
+
+extern "C" int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K,
+                               int64_t lda, int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux,
+                               int64_t ldaux, const float* lr, float scale, int tile, float* workspace,
+                               int64_t workspace_floats, int splits, void* stream) {
   if (A == nullptr || B == nullptr || C == nullptr) return DTF_ERR_NULL;
   if (M < 1 || N < 1 || K < 1 || ldc < N) return DTF_ERR_SHAPE;
   if (layout < DTF_GEMM_NN || layout > DTF_GEMM_TN || epi < DTF_EPI_NONE || epi > DTF_EPI_SGD) return DTF_ERR_SHAPE;
@@ -447,6 +544,9 @@ extern "C" int dtf_gemm_f32(int layout, int epi, const float* A, const float* B,
   a.epi = epi; a.act = act;
   a.bias = bias; a.aux = aux; a.ldaux = ldaux;
   a.lr = lr; a.scale = scale;
+  a.ws = workspace_floats > 1024 ? workspace : nullptr;
+  a.ws_floats = workspace_floats;
+  a.splits = splits;
   // 16-byte loads along k need K, the leading dimension and the base address to be multiples of four floats (a
   // compile-time variant: every operand of the layout whose k runs along memory must qualify)
   const bool vecA = (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
@@ -464,8 +564,17 @@ extern "C" int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out,
   if (M < 1 || N < 1 || ldz < N) return DTF_ERR_SHAPE;
   if (mode != DTF_EPI_NONE && mode != DTF_EPI_SGD) return DTF_ERR_SHAPE;
   if (mode == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), z, (long)ldz, M,
-                     N, out, mode, scale, lr);
+  const int segments = (M + kColsumRows - 1) / kColsumRows;
+  if (segments > 1 && mode == DTF_EPI_NONE && dtf_launch_zero(out, N, static_cast<hipStream_t>(stream)) != DTF_OK)
+    return DTF_ERR_LAUNCH;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, segments), dim3(1024), 0, static_cast<hipStream_t>(stream), z,
+                     (long)ldz, M, N, out, mode, scale, lr);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_dense_step_begin(float* loss_sum, int32_t* correct, float* global_step, void* stream) {
+  hipLaunchKernelGGL(dense_step_begin_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), loss_sum, correct,
+                     global_step);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

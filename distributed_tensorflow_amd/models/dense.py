@@ -17,7 +17,8 @@ every launch a kernel of ``csrc/gemm.hip``:
             tfdist_between.py:65-66) or a plain store into a gradient tensor (parameter-server modes), and the bias
             gradient as a column sum with the same two endings.
 
-3 L + 1 launches per fused step (L = number of layers), all on the current stream, captured into hipGraph chunks by
+4 L + 1 launches per fused step (L = number of layers, with biases; one of them clears the step's loss / accuracy
+accumulators and bumps the step counter), all on the current stream, captured into hipGraph chunks by
 ``run_chunk`` when the mini-batches come from a resident set.  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
@@ -106,10 +107,15 @@ class DenseStackEngine:
         self._host_cursor = 0
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._eval_bufs: Dict[int, list] = {}
+        # K-split workspace of this engine's GEMMs (a batch-100 layer has 26 tiles for 256 CUs): 34 MB, one per engine,
+        # so two engines on two streams never share counters
+        self._ws = hb.gemm_workspace(dev) if self.on_gpu else None
 
     @property
     def launches_per_step(self) -> int:
-        return 3 * self.L + 1 + (1 if self.global_step is not None else 0)
+        """Accumulator reset + step counter, L forward GEMMs, the head, L - 1 input gradients, L weight and L bias
+        gradients (biases that exist)."""
+        return 3 * self.L + 1 + sum(1 for b in self.b if b is not None)
 
     # -- data -----------------------------------------------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -147,15 +153,17 @@ class DenseStackEngine:
         h = x
         for i in range(self.L):
             act = self.acts[i] if i < self.L - 1 else hb.ACT_NONE
-            hb.gemm(hb.GEMM_NN, h, self.W[i], out=acts_out[i], epi=hb.EPI_BIAS_ACT, act=act, bias=self.b[i])
+            hb.gemm(hb.GEMM_NN, h, self.W[i], out=acts_out[i], epi=hb.EPI_BIAS_ACT, act=act, bias=self.b[i],
+                    workspace=self._ws)
             h = acts_out[i]
         return h
 
     def _step_gpu(self, bi: int, fused: bool, scale: float):
         x, y = self._batch(bi)
         slot = self._slot(bi)
-        self.loss_sum[slot:slot + 1].zero_()
-        self.correct[slot:slot + 1].zero_()
+        # (the counter's bump commutes with everything else in the step: nothing in it reads global_step)
+        hb.dense_step_begin(self.loss_sum[slot:slot + 1], self.correct[slot:slot + 1],
+                            self.global_step if fused else None)
         logits = self._forward_gpu(x, self.a)
         hb.softmax_xent(logits, y, dz=self.dz[-1], grad_scale=(1.0 if fused else scale) / self.B,
                         loss_sum=self.loss_sum[slot:slot + 1], correct=self.correct[slot:slot + 1])
@@ -163,18 +171,17 @@ class DenseStackEngine:
             below = self.a[i - 1] if i > 0 else x
             if i > 0:       # before W_i changes: dz_{i-1} = (dz_i W_i^T) * act'(a_{i-1})
                 hb.gemm(hb.GEMM_NT, self.dz[i], self.W[i], out=self.dz[i - 1], epi=hb.EPI_ACT_BWD,
-                        act=self.acts[i - 1], aux=below)
+                        act=self.acts[i - 1], aux=below, workspace=self._ws)
             if fused:
-                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.W[i], epi=hb.EPI_SGD, lr=self.lr, scale=1.0)
+                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.W[i], epi=hb.EPI_SGD, lr=self.lr, scale=1.0,
+                        workspace=self._ws)
                 if self.b[i] is not None:
                     hb.colsum(self.dz[i], out=self.b[i], sgd=True, lr=self.lr)
             else:
                 gw, gb = self.g[i]
-                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=gw)
+                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=gw, workspace=self._ws)
                 if self.b[i] is not None:
                     hb.colsum(self.dz[i], out=gb)
-        if fused and self.global_step is not None:
-            self.global_step.add_(1.0)
 
     def _step_cpu(self, bi: int, fused: bool, scale: float):
         x, y = self._batch(bi)

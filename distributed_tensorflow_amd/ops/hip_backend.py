@@ -141,9 +141,13 @@ def _declare(lib: C.CDLL) -> None:
                  "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_gemm_f32.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, i64, vp, f32, i32, vp]
+    lib.dtf_gemm_f32_ws.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, i64, vp, f32, i32, vp,
+                                    i64, i32, vp]
+    lib.dtf_gemm_f32_ws.restype = C.c_int
     lib.dtf_colsum.argtypes = [vp, i64, i32, i32, vp, i32, f32, vp, vp]
     lib.dtf_softmax_xent.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]
-    for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent"):
+    lib.dtf_dense_step_begin.argtypes = [vp, vp, vp, vp]
+    for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent", "dtf_dense_step_begin"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_debug_force_generic_path.argtypes = [i32]
     lib.dtf_debug_force_generic_path.restype = None
@@ -304,8 +308,12 @@ def _f32_2d(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EPI_NONE, act: int = ACT_NONE,
          bias: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, lr: Optional[torch.Tensor] = None,
-         scale: float = 1.0, tile: int = 0) -> torch.Tensor:
+         scale: float = 1.0, tile: int = 0, workspace: Optional[torch.Tensor] = None, splits: int = 0) -> torch.Tensor:
     """``out = epilogue(op(A) @ op(B))`` on the fp32 matrix cores (csrc/gemm.hip).
+
+    ``workspace``: a float32 tensor on the same device, zero-filled once by the caller and from then on used only by
+    calls on one stream at a time (``gemm_workspace()``); with it, shapes with few tiles and a long K are split along K
+    over several workgroups per tile (``splits``: 0 = chosen from the shape, n = at most n).
 
     layout ``GEMM_NN``: A [M,K], B [K,N]; ``GEMM_NT``: A [M,K], B [N,K]; ``GEMM_TN``: A [K,M], B [K,N].  Operands are
     row-major with contiguous rows (row strides may exceed the row length).  Epilogues: ``EPI_NONE`` ``scale * acc``;
@@ -336,10 +344,18 @@ def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EP
         raise HipKernelError("gemm: the activation-gradient epilogue needs the activation's output, shaped like out")
     if epi == EPI_SGD and (lr is None or _f32c(lr, "lr").numel() != 1):
         raise HipKernelError("gemm: the SGD epilogue needs a one-element device learning rate")
-    _check(lib.dtf_gemm_f32(layout, epi, _ptr(A), _ptr(B), _ptr(out), M, N, K, A.stride(0), B.stride(0), out.stride(0),
-                            int(act), _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0, _ptr(lr),
-                            float(scale), int(tile), _stream()), "dtf_gemm_f32")
+    if workspace is not None and (_f32c(workspace, "workspace").device != A.device):
+        raise HipKernelError("gemm: the workspace must live on the operands' device")
+    _check(lib.dtf_gemm_f32_ws(layout, epi, _ptr(A), _ptr(B), _ptr(out), M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                               int(act), _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0, _ptr(lr),
+                               float(scale), int(tile), _ptr(workspace), workspace.numel() if workspace is not None else 0,
+                               int(splits), _stream()), "dtf_gemm_f32")
     return out
+
+
+def gemm_workspace(device, tiles: int = 128, splits: int = 16) -> torch.Tensor:
+    """A zero-filled workspace large enough for any K split ``gemm`` chooses (at most 128 tiles of 64 x 64 x 16 ranges)."""
+    return torch.zeros(1024 + tiles * splits * 64 * 64, dtype=torch.float32, device=device)
 
 
 def colsum(z, out: Optional[torch.Tensor] = None, *, sgd: bool = False, lr: Optional[torch.Tensor] = None,
@@ -382,6 +398,14 @@ def softmax_xent(logits, labels, *, dz: Optional[torch.Tensor] = None, grad_scal
         raise HipKernelError("softmax_xent: row_loss has one element per row")
     _check(lib.dtf_softmax_xent(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(loss_sum),
                                 _ptr(correct), _ptr(row_loss), _stream()), "dtf_softmax_xent")
+
+
+def dense_step_begin(loss_sum: Optional[torch.Tensor], correct: Optional[torch.Tensor],
+                     global_step: Optional[torch.Tensor]):
+    """One launch at the start of a dense-stack step: clears the step's loss / accuracy accumulators (one float, one
+    int32) and bumps the step counter (one float); each may be None."""
+    _check(require().dtf_dense_step_begin(_ptr(loss_sum), _ptr(correct), _ptr(global_step), _stream()),
+           "dtf_dense_step_begin")
 
 
 def sgd_apply_(p, g, lr: torch.Tensor, scale: float = 1.0, zero_grad: bool = False,

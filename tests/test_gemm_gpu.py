@@ -143,3 +143,45 @@ def test_gemm_rejects_mismatched_operands():
         hb.gemm(hb.GEMM_NN, _rand(4, 5), _rand(5, 7), out=torch.zeros(4, 8, device=DEV))
     with pytest.raises(hb.HipKernelError):
         hb.gemm(hb.GEMM_NN, _rand(4, 5), _rand(5, 7), epi=hb.EPI_ACT_BWD)
+
+
+@pytest.mark.parametrize("layout", [hb.GEMM_NN, hb.GEMM_NT, hb.GEMM_TN])
+@pytest.mark.parametrize("M,N,K,splits", [(100, 1024, 784, 0), (100, 784, 1024, 0), (64, 64, 4096, 16), (33, 130, 517, 3),
+                                          (100, 10, 2048, 0), (7, 5, 129, 2)])
+def test_gemm_k_split_matches_oracle_and_leaves_counters_clean(layout, M, N, K, splits):
+    a, b, want = _operands(layout, M, N, K, seed=21)
+    ws = hb.gemm_workspace(DEV)
+    for _ in range(3):          # the counters must be back at zero after every launch
+        got = hb.gemm(layout, a, b, workspace=ws, splits=splits)
+        torch.testing.assert_close(got, want.float(), rtol=2e-5, atol=2e-5 * K ** 0.5)
+    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
+    # same bits whatever the arrival order of the workgroups: a fixed order of the partial sums
+    again = hb.gemm(layout, a, b, workspace=ws, splits=splits)
+    assert torch.equal(got, again)
+
+
+def test_gemm_k_split_with_every_epilogue():
+    ws = hb.gemm_workspace(DEV)
+    x, W, bias = _rand(100, 784, seed=3), _rand(784, 300, scale=0.1, seed=4), _rand(300, seed=5)
+    got = hb.gemm(hb.GEMM_NN, x, W, epi=hb.EPI_BIAS_ACT, act=0, bias=bias, workspace=ws)
+    torch.testing.assert_close(got, torch.sigmoid(x.double() @ W.double() + bias.double()).float(), rtol=2e-5, atol=2e-5)
+    dz, W2 = _rand(100, 1024, scale=0.1, seed=6), _rand(200, 1024, seed=7)
+    a = torch.sigmoid(_rand(100, 200, seed=8))
+    got = hb.gemm(hb.GEMM_NT, dz, W2, epi=hb.EPI_ACT_BWD, act=0, aux=a, workspace=ws)
+    want = ((dz.double() @ W2.double().t()) * (a.double() * (1 - a.double()))).float()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    xb, dzb, Wb = _rand(2048, 100, seed=9), _rand(2048, 64, scale=0.01, seed=10), _rand(100, 64, seed=11)
+    W0 = Wb.clone()
+    lr = torch.tensor([0.05], device=DEV)
+    hb.gemm(hb.GEMM_TN, xb, dzb, out=Wb, epi=hb.EPI_SGD, lr=lr, scale=0.5, workspace=ws)
+    torch.testing.assert_close(Wb, (W0.double() - 0.025 * (xb.double().t() @ dzb.double())).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_colsum_tall_matrix_uses_row_segments():
+    z = _rand(5000, 130, scale=0.1, seed=12)
+    torch.testing.assert_close(hb.colsum(z), z.double().sum(0).float(), rtol=1e-4, atol=1e-4)
+    b = _rand(130, seed=13)
+    b0 = b.clone()
+    lr = torch.tensor([0.1], device=DEV)
+    hb.colsum(z, out=b, sgd=True, lr=lr)
+    torch.testing.assert_close(b, (b0.double() - 0.1 * z.double().sum(0)).float(), rtol=1e-4, atol=1e-4)
