@@ -36,9 +36,12 @@ def main():
     ap.add_argument("--shapes", default=DEFAULT)
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--workspace", type=int, default=1, help="1: let shapes with few tiles split K (the engines' setting)")
+    ap.add_argument("--split_knobs", default="", help="max_tiles,target_workgroups of the K split (tuning)")
     a = ap.parse_args()
+    if a.split_knobs:
+        hb.require().dtf_debug_set_gemm_split(*(int(v) for v in a.split_knobs.split(",")))
     dev = torch.device("cuda")
-    ws = hb.gemm_workspace(dev) if a.workspace else None
+    ws = hb.gemm_workspace(dev, tiles=1024, splits=8) if a.workspace else None
     print(f"{'M x N x K':>20} {'layout':>6} {'tile':>4} {'ours us':>10} {'TFLOP/s':>8} {'library us':>10} {'TFLOP/s':>8} {'ours/lib':>8} {'max diff':>9}")
     for shape in a.shapes.split(","):
         M, N, K = (int(v) for v in shape.split("x"))

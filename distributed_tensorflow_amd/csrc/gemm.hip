@@ -361,6 +361,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
   }
 }
 
+int g_split_max_tiles = 128, g_split_target = 256;       // tuning knobs of the K split (dtf_debug_set_gemm_split)
+
 template <int BM, int BN, int LAYOUT, bool VEC>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int bytes = 2 * kKQ * (BM + BN) * 4 * (int)sizeof(float);
@@ -380,8 +382,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   // Needs the caller's workspace: 1024 counters + splits x tiles x BM x BN floats.
   const long T = (long)b.tiles_m * b.tiles_n, chunks = (a.K + kChunk - 1) / kChunk;
   int splits = 1;
-  if (a.ws != nullptr && T <= 128 && chunks >= 4) {
-    long want = a.splits > 0 ? a.splits : 256 / T;            // fill the chip once
+  if (a.ws != nullptr && T <= g_split_max_tiles && chunks >= 4) {
+    long want = a.splits > 0 ? a.splits : g_split_target / T;  // fill the chip once
     if (want > chunks / 2) want = chunks / 2;                  // at least two chunks per workgroup
     if (want > 16) want = 16;
     const long room = (a.ws_floats - 1024) / (T * BM * BN);
@@ -399,9 +401,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 
 template <int LAYOUT, bool VEC>
 int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
-  // the 128-tile once it fills the chip (a workgroup per CU), the 64-tile below that
+  // Which tile: the one whose rounds of co-resident workgroups end first.  512 large tiles (two per CU) or 1024 small
+  // ones (four per CU) run together; a round of small tiles does half the work of a round of large ones at about 0.9 of
+  // the rate (measured: 2048^3 as 1024 small tiles 113 TFLOP/s, 4096^3 as 1024 large tiles 124), so a large-tile grid
+  // that would leave its last round mostly empty (3072^3: 576 tiles) is better served by small tiles.
   const long big = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (tile == 128 || (tile == 0 && big >= 256)) return launch_gemm<128, 128, LAYOUT, VEC>(a, stream);
+  const long small = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  const double t_big = (double)((big + 511) / 512), t_small = 0.55 * (double)((small + 1023) / 1024);
+  if (tile == 128 || (tile == 0 && big >= 512 && t_big <= t_small)) return launch_gemm<128, 128, LAYOUT, VEC>(a, stream);
   return launch_gemm<64, 64, LAYOUT, VEC>(a, stream);
 }
 
@@ -516,6 +523,11 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 }
 
 }  // namespace
+
+extern "C" void dtf_debug_set_gemm_split(int max_tiles, int target_workgroups) {
+  g_split_max_tiles = max_tiles;
+  g_split_target = target_workgroups;
+}
 
 extern "C" int dtf_gemm_f32(int layout, int epi, const float* A, const float* B, float* C, int M, int N, int K,
                             int64_t lda, int64_t ldb, int64_t ldc, int act, const float* bias, const float* aux,

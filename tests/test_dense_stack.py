@@ -241,3 +241,25 @@ def test_tfsingle_script_with_hidden_layers(tmp_path):
         assert "Step: 44,  Epoch:  2,  Batch:  22 of  22" in out.stdout and out.stdout.rstrip().endswith("Done")
         accs = [float(line.split(":")[1]) for line in out.stdout.splitlines() if line.startswith("Test-Accuracy")]
         assert len(accs) == 2 and accs[-1] > 0.5
+
+
+@pytest.mark.parametrize("bucket_mb", [32.0, 0.001])
+def test_data_parallel_dense_stack_applies_the_mean_gradient(bucket_mb):
+    """Two gloo ranks: bucketed all-reduce + SGD per bucket = one process applying the mean of both gradients."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from cluster_utils import ROOT, free_ports
+
+    port = free_ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dense_dp_worker.py"), str(bucket_mb)]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert res["replicas_identical"] and res["global_step"] == 14
+    assert res["one_step_error"] < 1e-5
+    assert res["buckets"] == (1 if bucket_mb > 1 else 3)        # 1 KB buckets: one per layer
+    assert res["acc"] > 0.5 and "all-reduce" in res["desc"]

@@ -147,3 +147,25 @@ def test_resident_trainer_graph_replay_equals_eager_across_reshuffles():
     for a, b in zip(finals[0][:-1], finals[1][:-1]):
         assert torch.equal(a, b)
     assert finals[0][-1][1] > 0.8
+
+
+def test_data_parallel_trainer_gpu_streams_match_cpu_run():
+    """One rank on the GPU (buckets reduced and applied on the side stream under the backward of the layers below)
+    against the same trainer on the CPU: same seed, same shuffles, same steps."""
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.parallel.dense_trainer import DenseDataParallelTrainer
+
+    rng = np.random.RandomState(7)
+    labels = rng.randint(0, 10, 1200)
+    images = (rng.rand(10, 784).astype(np.float32)[labels] + 0.3 * rng.rand(1200, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    runs = []
+    for dev in ("cpu", "cuda"):
+        ds = DeviceDataset(images, onehot, torch.device(dev), 100, seed=5)
+        tr = DenseDataParallelTrainer((784, 256, 128, 10), ("relu", "sigmoid"), ds, 100, 0.1, dev, seed=3, bucket_mb=0.1)
+        assert len(tr.buckets) == 2
+        tr.run_steps(15)            # 12 batches per epoch: one reshuffle
+        runs.append((tr.params.cpu(), tr.global_step_value(), tr.last_loss()))
+    assert runs[0][1] == runs[1][1] == 15
+    torch.testing.assert_close(runs[1][0], runs[0][0], rtol=2e-4, atol=2e-5)
+    assert abs(runs[0][2] - runs[1][2]) < 1e-3
