@@ -4,6 +4,7 @@ set -o pipefail
 root=$PWD; out=$root/gpurun_out/dense; mkdir -p $out
 timeout -k 10 200 python -u bench/gemm_bench.py --tiles 0 > $out/gemm_vs_library.txt 2>&1 || exit 1
 timeout -k 10 300 python -u bench/dense_bench.py > $out/dense_steps.txt 2>&1 || exit 1
+timeout -k 10 200 python bench/dense_dp_bench.py > $out/dense_dp_1rank.json 2>/dev/null || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/tfsingle.py --resident --hidden 512,256 --activation relu --lr 0.05 --epochs 3 --logs_path /tmp/lg_dense > $out/tfsingle_512_256.txt 2>&1 || exit 1
 cd $root

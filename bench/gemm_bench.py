@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.ops import hip_backend as hb  # noqa: E402
 
-DEFAULT = "4096x4096x4096,8192x8192x4096,2048x2048x2048,1024x1024x1024,10000x100x784,4096x1024x784,100x1024x784,100x784x1024,784x1024x100"
+DEFAULT = "4096x4096x4096,8192x8192x4096,3072x3072x3072,2048x2048x2048,1024x1024x1024,10000x100x784,4096x1024x784,100x1024x784,100x784x1024,784x1024x100"
 
 
 def timed(fn, iters):
