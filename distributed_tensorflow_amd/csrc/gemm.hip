@@ -41,7 +41,6 @@
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kKQ = 8;                // k-quads per chunk
 constexpr int kChunk = 4 * kKQ;       // k per chunk
 constexpr int kGroupM = 8;            // tile rows per group of the tile order
@@ -64,11 +63,11 @@ struct GemmArgs {
   float* ws;               // splits > 1: [1024 tile counters, zero between launches][splits][tiles][BM * BN] partial sums
 };
 
-// What one thread moves per chunk for one operand: NS = R / 32 slots of four k each.
+// What one thread moves per chunk for one operand: NS = 8 R / threads slots of four k each (NW waves per workgroup).
 //
 // Slot j of a thread, by layout of the operand in memory:
-//   k along memory (KC)   row 8 (wave + 4 j) + (lane & 7), k-quad lane >> 3      (8 rows x 128 bytes per instruction)
-//   k strided             row or column tid % R, k-quad tid / R + (256 / R) j    (256-byte row segments)
+//   k along memory (KC)   row 8 (wave + NW j) + (lane & 7), k-quad lane >> 3         (8 rows x 128 bytes per instruction)
+//   k strided             row or column tid % R, k-quad tid / R + (threads / R) j    (256-byte row segments)
 // Every load is a buffer load: the descriptor points at the tile (KC) or at the tile's rows of the chunk (strided), the
 // per-lane part of the address is a 32-bit byte offset computed ONCE (rows and columns past the edge of the operand
 // clamped to its last one), and what changes per chunk, slot and k is a scalar offset - no vector arithmetic per load.
@@ -76,12 +75,13 @@ struct GemmArgs {
 // matrix pipe does not hide: 103 -> 118 TFLOP/s at 4096^3 NN.)  Only in the last chunk of a K that is not a multiple of
 // 32 are lanes whose k lies past the end redirected to the chunk's first k; rows, columns and k past the edge are zeroed
 // on their way to LDS.
-template <int R, bool KC, bool VEC, int D>
+template <int R, bool KC, bool VEC, int D, int NW>
 struct Stager {
-  static constexpr int NS = R / 32;
+  static constexpr int NT = NW * 64;                        // threads of the workgroup
+  static constexpr int NS = R * kKQ / NT;
   static constexpr int NV = KC ? NS : 1;                    // distinct per-lane offsets
-  static constexpr int kQStep = KC ? 0 : kThreads / R;      // k-quads between the slots of a thread (strided form)
-  static constexpr int kLdsStep = KC ? 32 * 4 : kQStep * R * 4;
+  static constexpr int kQStep = KC ? 0 : NT / R;            // k-quads between the slots of a thread (strided form)
+  static constexpr int kLdsStep = KC ? 8 * NW * 4 : kQStep * R * 4;
   const float* origin;     // first element of the tile: (row r0, k 0) or (k 0, column r0)
   long ld;
   int K;
@@ -106,7 +106,7 @@ struct Stager {
     if (KC) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const int r = 8 * (wave + 4 * j) + (lane & 7);
+        const int r = 8 * (wave + NW * j) + (lane & 7);
         ok[j] = r0 + r < rows;
         voff[j] = (unsigned)(((long)(ok[j] ? r : rows - 1 - r0) * ld + 4 * (lane >> 3)) * 4);
       }
@@ -169,10 +169,15 @@ struct Stager {
   }
 };
 
-template <int BM, int BN, int LAYOUT, bool VEC>
-__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
+template <int BM, int BN, int LAYOUT, bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr bool AK = LAYOUT != DTF_GEMM_TN, BK = LAYOUT == DTF_GEMM_NT;
-  constexpr int TM = BM / 32, TN = BN / 32;            // 16 x 16 blocks per wave in each direction
+  constexpr int kThreads = NW * 64;
+  // The waves of a workgroup tile its output 2 x 2 (four waves) or 2 x 4 (eight waves).  Only four are instantiated:
+  // eight waves on the 128-tile (four per SIMD with two workgroups per CU, 128 registers each) measured 108 - 120 TFLOP/s
+  // against 117 - 126 with four, and did not fit its registers.
+  constexpr int WGN = NW / 2;
+  constexpr int TM = BM / 32, TN = BN / (16 * WGN);    // 16 x 16 blocks per wave in each direction
   constexpr int kAs = kKQ * BM * 4, kBs = kKQ * BN * 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][kAs]
@@ -195,13 +200,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+  const int wm0 = (wave / WGN) * (BM / 2), wn0 = (wave % WGN) * (BN / WGN);
 
   // Chunks in flight between memory and LDS.  Two or three for the small tile (-DDTF_GEMM_DEPTH64=2|3) measured the
   // same as one (100 x 784 x 1024: 37 us with each): a chunk of the small tile is not waiting for memory.
   constexpr int D = BM <= 64 ? DTF_GEMM_DEPTH64 : 1;
-  Stager<BM, AK, VEC, D> sa;
-  Stager<BN, BK, VEC, D> sb;
+  Stager<BM, AK, VEC, D, NW> sa;
+  Stager<BN, BK, VEC, D, NW> sb;
   sa.init(a.A, a.lda, a.M, m0, a.K, tid);
   sb.init(a.B, a.ldb, a.N, n0, a.K, tid);
 
@@ -363,14 +368,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs a) {
 
 int g_split_max_tiles = 128, g_split_target = 256;       // tuning knobs of the K split (dtf_debug_set_gemm_split)
 
-template <int BM, int BN, int LAYOUT, bool VEC>
+template <int BM, int BN, int LAYOUT, bool VEC, int NW = 4>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  constexpr int kThreads = NW * 64;
   constexpr int bytes = 2 * kKQ * (BM + BN) * 4 * (int)sizeof(float);
   static unsigned long long configured = 0;            // one bit per device: the attribute belongs to the device's copy
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
   if (dev >= 64 || !((configured >> dev) & 1ull)) {
-    if (hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, LAYOUT, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, LAYOUT, VEC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             bytes) != hipSuccess)
       return DTF_ERR_LAUNCH;
     if (dev < 64) configured |= 1ull << dev;
@@ -394,7 +400,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     }
   }
   b.splits = splits;
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC>), dim3((unsigned)(T * splits)), dim3(kThreads), bytes, stream,
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LAYOUT, VEC, NW>), dim3((unsigned)(T * splits)), dim3(kThreads), bytes, stream,
                      b);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
@@ -408,7 +414,7 @@ int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
   const long big = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
   const long small = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   const double t_big = (double)((big + 511) / 512), t_small = 0.55 * (double)((small + 1023) / 1024);
-  if (tile == 128 || (tile == 0 && big >= 512 && t_big <= t_small)) return launch_gemm<128, 128, LAYOUT, VEC>(a, stream);
+  if (tile == 128 || (tile == 0 && big >= 512 && t_big <= t_small)) return launch_gemm<128, 128, LAYOUT, VEC, 4>(a, stream);
   return launch_gemm<64, 64, LAYOUT, VEC>(a, stream);
 }
 
