@@ -16,7 +16,13 @@ dev = torch.device("cuda")
 A = torch.randn((K, M) if layout == hb.GEMM_TN else (M, K), device=dev)
 B = torch.randn((N, K) if layout == hb.GEMM_NT else (K, N), device=dev)
 out = torch.empty(M, N, device=dev)
+library = os.environ.get("DTF_GEMM_ONCE_LIBRARY") == "1"       # the library GEMM instead (for counter comparisons)
+At = A.t() if layout == hb.GEMM_TN else A
+Bt = B.t() if layout == hb.GEMM_NT else B
 for _ in range(iters):
-    hb.gemm(layout, A, B, out=out, tile=tile)
+    if library:
+        torch.matmul(At, Bt, out=out)
+    else:
+        hb.gemm(layout, A, B, out=out, tile=tile)
 torch.cuda.synchronize()
 print("done", float(out[0, 0]))

@@ -1,0 +1,22 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from distributed_tensorflow_amd.ops import hip_backend as hb
+lib = hb.require()
+dev = torch.device("cuda")
+M = N = K = 4096
+A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); out = torch.empty(M, N, device=dev)
+Bn = torch.randn(K, N, device=dev)
+def timed(fn, iters=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / iters
+for parts, what in ((15, "all"), (11, "no barrier"), (14, "no global loads"), (13, "no LDS writes"), (7, "no LDS reads"), (12, "no loads, no LDS writes"), (4, "MFMA + barrier only"), (0, "MFMA only")):
+    lib.dtf_debug_set_gemm_parts(parts)
+    t_nt = timed(lambda: hb.gemm(hb.GEMM_NT, A, B, out=out))
+    t_nn = timed(lambda: hb.gemm(hb.GEMM_NN, A, Bn, out=out))
+    f = 2.0 * M * N * K
+    print(f"{what:28s} NT {t_nt:8.1f} us {f/t_nt/1e6:6.1f} TFLOP/s   NN {t_nn:8.1f} us {f/t_nn/1e6:6.1f} TFLOP/s", flush=True)

@@ -150,6 +150,39 @@ struct Stager {
         }
     }
   }
+  // The same two steps for a tile that lies inside the operand and a chunk that lies inside K: straight-line code (no
+  // test, no clamp), so that the caller can pin its instructions between the MFMAs of a chunk.
+  static constexpr int kLoads = (KC && VEC) ? NS : 4 * NS;        // load instructions per chunk
+  template <int S>
+  __device__ __forceinline__ void issue_fast(int k0) {
+    if (KC) {
+      const __amdgpu_buffer_rsrc_t rsrc = descriptor(origin);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (VEC) {
+          v[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 4, 0));
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + 4 * s, k0 * 4, 0));
+        }
+      }
+    } else {
+      const __amdgpu_buffer_rsrc_t rsrc = descriptor(origin + (long)k0 * ld);
+      const int kq_w = __builtin_amdgcn_readfirstlane(tid / R);
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rsrc, voff[0], (int)((4 * (kq_w + kQStep * j) + s) * ld * 4), 0));
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void write_fast(float* img) const {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) *reinterpret_cast<f32x4*>(img + lds0 + kLdsStep * j) = v[S][j];
+  }
   template <int S>
   __device__ __forceinline__ void write(int k0, float* img) const {
     if (interior && k0 + kChunk <= K) {
@@ -271,6 +304,72 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
     if (more) read_ops(An, Bn, 0, av[0], bv[0]);
     multiply(av[1], bv[1], 3, 4);
   };
+  // The steady-state chunk (tile inside both operands, chunks c+1 and c+1+D inside K): the same steps as straight-line
+  // code with their order PINNED, every LDS and memory instruction issued in the shadow of a matrix instruction - a wave
+  // issues in order, and an MFMA occupies the matrix pipe for 32 cycles of which its own issue takes 4: one or two other
+  // instructions fit behind each, a block of sixteen of them does not (measured with parts of the chunk switched off:
+  // the unpinned chunk loses 15 % to each of its load, LDS-write, LDS-read and barrier blocks on its own).
+  constexpr int kMfma = 0x008, kVmemRead = 0x020, kDsRead = 0x100, kDsWrite = 0x200;
+  constexpr int NRD = TM + TN;                                   // LDS reads of one macro-step
+  constexpr int MF = 4 * TM * TN;                                // MFMAs of one macro-step
+  constexpr int NWR = Stager<BM, AK, VEC, D, NW>::NS + Stager<BN, BK, VEC, D, NW>::NS;
+  constexpr int NVM = Stager<BM, AK, VEC, D, NW>::kLoads + Stager<BN, BK, VEC, D, NW>::kLoads;
+  auto chunk_fast = [&](int c, auto parity) {
+    constexpr int S = (decltype(parity)::value + 1) % D;
+    const float* Ac = As + (c & 1) * kAs;
+    const float* Bc = Bs + (c & 1) * kBs;
+    float* An = As + ((c + 1) & 1) * kAs;
+    float* Bn = Bs + ((c + 1) & 1) * kBs;
+    read_ops(Ac, Bc, 1, av[1], bv[1]);
+    multiply(av[0], bv[0], 0, 4);
+    sa.template write_fast<S>(An);
+    sb.template write_fast<S>(Bn);
+    sa.template issue_fast<S>((cbeg + c + 1 + D) * kChunk);
+    sb.template issue_fast<S>((cbeg + c + 1 + D) * kChunk);
+    multiply(av[1], bv[1], 0, 3);
+    {   // macro-step 0: the operand reads of macro-step 1 spread over its first half
+      constexpr int per = MF / (2 * NRD) > 0 ? MF / (2 * NRD) : 1;
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(kDsRead, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kMfma, per, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(kMfma, MF - per * NRD, 0);
+      // three quarters of macro-step 1: an LDS write behind each of the first MFMAs, then the loads of chunk c+1+D
+      constexpr int M1 = 3 * TM * TN;
+      constexpr int left = M1 - NWR > 0 ? M1 - NWR : 1;          // MFMAs left for the loads
+      constexpr int lper = (NVM + left - 1) / left;              // loads behind one MFMA
+      constexpr int lgroups = (NVM + lper - 1) / lper;
+#pragma unroll
+      for (int i = 0; i < NWR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(kDsWrite, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kMfma, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < lgroups; ++i) {
+        __builtin_amdgcn_sched_group_barrier(kVmemRead, lper, 0);
+        __builtin_amdgcn_sched_group_barrier(kMfma, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(kMfma, M1 - NWR - lgroups > 0 ? M1 - NWR - lgroups : 0, 0);
+    }
+    __syncthreads();
+    read_ops(An, Bn, 0, av[0], bv[0]);
+    multiply(av[1], bv[1], 3, 4);
+    {   // the last quarter: the operand reads of the next chunk's macro-step 0 behind its MFMAs
+      constexpr int M3 = TM * TN;
+      constexpr int per = M3 / NRD > 0 ? M3 / NRD : 1;
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(kDsRead, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(kMfma, per, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(kMfma, M3 - per * NRD > 0 ? M3 - per * NRD : 0, 0);
+    }
+  };
+  const bool steady = sa.interior && sb.interior;
+  // chunk c may take the pinned form when chunks c+1 and c+1+D exist and are full
+  auto fast_ok = [&](int c) { return steady && c + 1 + D < nchunks && (cbeg + c + 2 + D) * kChunk <= a.K; };
+
   sa.template issue<0>(cbeg * kChunk);
   sb.template issue<0>(cbeg * kChunk);
   sa.template write<0>(cbeg * kChunk, As);
@@ -289,10 +388,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
   }
   __syncthreads();
   read_ops(As, Bs, 0, av[0], bv[0]);
-  for (int c = 0; c < nchunks; c += D) {
-    chunk(c, std::integral_constant<int, 0>{});
-    if (D > 1 && c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1 % D>{});
-    if (D > 2 && c + 2 < nchunks) chunk(c + 2, std::integral_constant<int, 2 % D>{});
+  {
+    int c = 0;
+    if (D == 1)                 // the steady state: pinned chunks (one register set: the parity plays no role)
+      for (; fast_ok(c); ++c) chunk_fast(c, std::integral_constant<int, 0>{});
+    for (; c < nchunks; c += D) {       // the last chunks, edge tiles, deeper prefetch: the same steps under conditions
+      chunk(c, std::integral_constant<int, 0>{});
+      if (D > 1 && c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1 % D>{});
+      if (D > 2 && c + 2 < nchunks) chunk(c + 2, std::integral_constant<int, 2 % D>{});
+    }
   }
 
   // ---- K split over several workgroups: partial sums meet in the workspace, the LAST workgroup of a tile to arrive
