@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
     if (more) read_ops(An, Bn, 0, av[0], bv[0]);
     multiply(av[1], bv[1], 3, 4);
   };
-  // The steady-state chunk (tile inside both operands, chunks c+1 and c+1+D inside K): the same steps as straight-line
+  // The steady-state chunk (chunks c+1 and c+1+D inside K): the same steps as straight-line
   // code with their order PINNED, every LDS and memory instruction issued in the shadow of a matrix instruction - a wave
   // issues in order, and an MFMA occupies the matrix pipe for 32 cycles of which its own issue takes 4: one or two other
   // instructions fit behind each, a block of sixteen of them does not (measured with parts of the chunk switched off:
@@ -366,9 +366,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
       __builtin_amdgcn_sched_group_barrier(kMfma, M3 - per * NRD > 0 ? M3 - per * NRD : 0, 0);
     }
   };
-  const bool steady = sa.interior && sb.interior;
-  // chunk c may take the pinned form when chunks c+1 and c+1+D exist and are full
-  auto fast_ok = [&](int c) { return steady && c + 1 + D < nchunks && (cbeg + c + 2 + D) * kChunk <= a.K; };
+  // Chunk c may take the pinned form when chunks c+1 and c+1+D exist and are full.  Edge tiles take it too: the per-lane
+  // offsets of rows and columns past the edge point at the operand's last row or column (valid memory), and what those
+  // lanes carry only reaches accumulators whose row or column the epilogue does not store.
+  auto fast_ok = [&](int c) { return c + 1 + D < nchunks && (cbeg + c + 2 + D) * kChunk <= a.K; };
 
   sa.template issue<0>(cbeg * kChunk);
   sb.template issue<0>(cbeg * kChunk);
