@@ -58,6 +58,8 @@ struct GemmArgs {
   const float* lr;         // DTF_EPI_SGD: device learning rate
   float scale;             // DTF_EPI_SGD: C -= lr * scale * acc;  DTF_EPI_NONE: C = scale * acc
   int tiles_m, tiles_n;
+  int parts;               // timing experiments (results then wrong, pinned chunk off): bit 0 loads, 1 LDS writes,
+                           //   2 barrier, 3 LDS reads; 15 = the kernel as it is
   int splits;              // workgroups per tile, each with a range of K (1: none)
   long ws_floats;          // size of ws
   float* ws;               // splits > 1: [1024 tile counters, zero between launches][splits][tiles][BM * BN] partial sums
@@ -289,12 +291,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
     float* An = As + ((c + 1) & 1) * kAs;
     float* Bn = Bs + ((c + 1) & 1) * kBs;
     const bool more = c + 1 < nchunks;
-    read_ops(Ac, Bc, 1, av[1], bv[1]);
+    if (a.parts & 8) read_ops(Ac, Bc, 1, av[1], bv[1]);
     multiply(av[0], bv[0], 0, 4);
     if (more) {
-      sa.template write<S>((cbeg + c + 1) * kChunk, An);
-      sb.template write<S>((cbeg + c + 1) * kChunk, Bn);
-      if (c + 1 + D < nchunks) {
+      if (a.parts & 2) {
+        sa.template write<S>((cbeg + c + 1) * kChunk, An);
+        sb.template write<S>((cbeg + c + 1) * kChunk, Bn);
+      }
+      if (c + 1 + D < nchunks && (a.parts & 1)) {
         sa.template issue<S>((cbeg + c + 1 + D) * kChunk);
         sb.template issue<S>((cbeg + c + 1 + D) * kChunk);
       }
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
   // Chunk c may take the pinned form when chunks c+1 and c+1+D exist and are full.  Edge tiles take it too: the per-lane
   // offsets of rows and columns past the edge point at the operand's last row or column (valid memory), and what those
   // lanes carry only reaches accumulators whose row or column the epilogue does not store.
-  auto fast_ok = [&](int c) { return c + 1 + D < nchunks && (cbeg + c + 2 + D) * kChunk <= a.K; };
+  auto fast_ok = [&](int c) { return (a.parts == 15) && c + 1 + D < nchunks && (cbeg + c + 2 + D) * kChunk <= a.K; };
 
   sa.template issue<0>(cbeg * kChunk);
   sb.template issue<0>(cbeg * kChunk);
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
   }
 }
 
+int g_parts = 15;                                        // dtf_debug_set_gemm_parts
 int g_split_max_tiles = 128, g_split_target = 256;       // tuning knobs of the K split (dtf_debug_set_gemm_split)
 
 template <int BM, int BN, int LAYOUT, bool VEC, int NW = 4>
@@ -635,6 +640,9 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 
 }  // namespace
 
+// Timing experiments on the UNPINNED chunk (see GemmArgs::parts); 15 restores the kernel.
+extern "C" void dtf_debug_set_gemm_parts(int parts) { g_parts = parts; }
+
 extern "C" void dtf_debug_set_gemm_split(int max_tiles, int target_workgroups) {
   g_split_max_tiles = max_tiles;
   g_split_target = target_workgroups;
@@ -670,6 +678,7 @@ extern "C" int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float*
   a.ws = workspace_floats > 1024 ? workspace : nullptr;
   a.ws_floats = workspace_floats;
   a.splits = splits;
+  a.parts = g_parts;
   // 16-byte loads along k need K, the leading dimension and the base address to be multiples of four floats (a
   // compile-time variant: every operand of the layout whose k runs along memory must qualify)
   const bool vecA = (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
