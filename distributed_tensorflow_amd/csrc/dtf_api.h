@@ -199,6 +199,11 @@ int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float* B, float* 
 // out[n] = scale * sum_m z[m*ldz + n]  (mode DTF_EPI_NONE)  or  out[n] -= lr[0] * scale * sum  (mode DTF_EPI_SGD)
 int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out, int mode, float scale, const float* lr,
                void* stream);
+// The head of a training step in one launch (M <= 8192 rows, one workgroup): *loss_out = sum of the row losses,
+// *correct_out = rows classified like their labels (both STORED, in a fixed order of additions), dz as above,
+// *global_step += 1 (each output may be null).
+int dtf_softmax_xent_step(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                          float* loss_out, int32_t* correct_out, float* global_step, void* stream);
 // Start of a training step of a dense stack: *loss_sum = 0, *correct = 0, *global_step += 1 (each may be null).
 int dtf_dense_step_begin(float* loss_sum, int32_t* correct, float* global_step, void* stream);
 // Softmax cross-entropy over logits [M][C] against (soft) labels [M][C]: loss_sum += sum of the row losses, correct +=

@@ -579,6 +579,44 @@ __global__ void dense_step_begin_kernel(float* loss_sum, int* correct, float* gl
 //   dz[m][c] = grad_scale * (softmax(z)[m][c] * sum_c' y[m][c'] - y[m][c])                      (dz may be null)
 // (the Softmax, Log, Mul, Sum, Mean, ArgMax, Equal nodes of tfdist_between.py:59-70 and their gradients, with the
 // logarithm taken of the shifted exponentials' sum instead of the probability.)  A wave per row, 4 rows per workgroup.
+// One row by one wave: returns the row's loss (every lane) and whether it is classified like its labels.
+__device__ __forceinline__ float xent_row(const float* __restrict__ zr, const float* __restrict__ yr, int C, int lane,
+                                          float* dzr, float grad_scale, int& hit) {
+  float mx = -INFINITY, ymx = -INFINITY;
+  int zi = 0x7fffffff, yi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = zr[c], t = yr[c];
+    if (v > mx) { mx = v; zi = c; }
+    if (t > ymx) { ymx = t; yi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {      // ties go to the smallest index (tf.argmax)
+    const float ov = __shfl_xor(mx, o, 64), oy = __shfl_xor(ymx, o, 64);
+    const int oi = __shfl_xor(zi, o, 64), oyi = __shfl_xor(yi, o, 64);
+    if (ov > mx || (ov == mx && oi < zi)) { mx = ov; zi = oi; }
+    if (oy > ymx || (oy == ymx && oyi < yi)) { ymx = oy; yi = oyi; }
+  }
+  float se = 0.f, ys = 0.f, yz = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float t = yr[c];
+    se += expf(zr[c] - mx);
+    ys += t;
+    yz += t * (zr[c] - mx);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    se += __shfl_xor(se, o, 64);
+    ys += __shfl_xor(ys, o, 64);
+    yz += __shfl_xor(yz, o, 64);
+  }
+  hit = zi == yi ? 1 : 0;
+  if (dzr != nullptr) {
+    const float inv = 1.f / se;
+    for (int c = lane; c < C; c += 64) dzr[c] = grad_scale * (expf(zr[c] - mx) * inv * ys - yr[c]);
+  }
+  return ys * logf(se) - yz;                // -sum_c y (z - mx - lse)
+}
+
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ z, const float* __restrict__ y,
                                                            int M, int C, float* dz, float grad_scale, float* loss_sum,
                                                            int* correct, float* row_loss) {
@@ -589,42 +627,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   float loss = 0.f;
   int hit = 0;
   if (m < M) {
-    const float* zr = z + (long)m * C;
-    const float* yr = y + (long)m * C;
-    float mx = -INFINITY, ymx = -INFINITY;
-    int zi = 0x7fffffff, yi = 0x7fffffff;
-    for (int c = lane; c < C; c += 64) {
-      const float v = zr[c], t = yr[c];
-      if (v > mx) { mx = v; zi = c; }
-      if (t > ymx) { ymx = t; yi = c; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {      // ties go to the smallest index (tf.argmax)
-      const float ov = __shfl_xor(mx, o, 64), oy = __shfl_xor(ymx, o, 64);
-      const int oi = __shfl_xor(zi, o, 64), oyi = __shfl_xor(yi, o, 64);
-      if (ov > mx || (ov == mx && oi < zi)) { mx = ov; zi = oi; }
-      if (oy > ymx || (oy == ymx && oyi < yi)) { ymx = oy; yi = oyi; }
-    }
-    float se = 0.f, ys = 0.f, yz = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float t = yr[c];
-      se += expf(zr[c] - mx);
-      ys += t;
-      yz += t * (zr[c] - mx);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      se += __shfl_xor(se, o, 64);
-      ys += __shfl_xor(ys, o, 64);
-      yz += __shfl_xor(yz, o, 64);
-    }
-    const float lse = logf(se);
-    loss = ys * lse - yz;                    // -sum_c y (z - mx - lse)
-    hit = zi == yi ? 1 : 0;
-    if (dz != nullptr) {
-      const float inv = 1.f / se;
-      for (int c = lane; c < C; c += 64) dz[(long)m * C + c] = grad_scale * (expf(zr[c] - mx) * inv * ys - yr[c]);
-    }
+    loss = xent_row(z + (long)m * C, y + (long)m * C, C, lane, dz != nullptr ? dz + (long)m * C : nullptr, grad_scale, hit);
     if (row_loss != nullptr && lane == 0) row_loss[m] = loss;
   }
   if (lane == 0) {
@@ -635,6 +638,41 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   if (threadIdx.x == 0) {
     if (loss_sum != nullptr) atomicAdd(loss_sum, (wl[0] + wl[1]) + (wl[2] + wl[3]));
     if (correct != nullptr) atomicAdd(correct, wc[0] + wc[1] + wc[2] + wc[3]);
+  }
+}
+
+// The head of a training step in ONE workgroup (batches of up to a few thousand rows): the 16 waves walk the rows 16
+// apart, the row losses are added in a fixed order, and the step's loss sum and correct count are STORED (no accumulator
+// to clear first, the same bits on every run) together with the bump of the step counter.
+__global__ __launch_bounds__(1024) void softmax_xent_step_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                                 int M, int C, float* dz, float grad_scale,
+                                                                 float* loss_out, int* correct_out, float* global_step) {
+  __shared__ float wl[16];
+  __shared__ int wc[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float loss = 0.f;
+  int hits = 0;
+  for (int m = wave; m < M; m += 16) {
+    int hit;
+    loss += xent_row(z + (long)m * C, y + (long)m * C, C, lane, dz != nullptr ? dz + (long)m * C : nullptr, grad_scale, hit);
+    hits += hit;
+  }
+  if (lane == 0) {
+    wl[wave] = loss;
+    wc[wave] = hits;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    int h = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      s += wl[w];
+      h += wc[w];
+    }
+    if (loss_out != nullptr) *loss_out = s;
+    if (correct_out != nullptr) *correct_out = h;
+    if (global_step != nullptr) *global_step += 1.0f;
   }
 }
 
@@ -701,6 +739,15 @@ extern "C" int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out,
     return DTF_ERR_LAUNCH;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, segments), dim3(1024), 0, static_cast<hipStream_t>(stream), z,
                      (long)ldz, M, N, out, mode, scale, lr);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_softmax_xent_step(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                                     float* loss_out, int32_t* correct_out, float* global_step, void* stream) {
+  if (logits == nullptr || labels == nullptr) return DTF_ERR_NULL;
+  if (M < 1 || C < 1 || M > 8192) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(softmax_xent_step_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, labels, M,
+                     C, dz, grad_scale, loss_out, correct_out, global_step);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

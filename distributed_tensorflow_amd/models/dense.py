@@ -17,8 +17,8 @@ every launch a kernel of ``csrc/gemm.hip``:
             tfdist_between.py:65-66) or a plain store into a gradient tensor (parameter-server modes), and the bias
             gradient as a column sum with the same two endings.
 
-4 L + 1 launches per fused step (L = number of layers, with biases; one of them clears the step's loss / accuracy
-accumulators and bumps the step counter), all on the current stream, captured into hipGraph chunks by
+4 L launches per fused step (L = number of layers, with biases; one more, which clears the step's loss / accuracy
+accumulators and bumps the step counter, for batches too tall for the one-workgroup head), all on the current stream, captured into hipGraph chunks by
 ``run_chunk`` when the mini-batches come from a resident set.  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
@@ -115,7 +115,7 @@ class DenseStackEngine:
     def launches_per_step(self) -> int:
         """Accumulator reset + step counter, L forward GEMMs, the head, L - 1 input gradients, L weight and L bias
         gradients (biases that exist)."""
-        return 3 * self.L + 1 + sum(1 for b in self.b if b is not None)
+        return 3 * self.L + sum(1 for b in self.b if b is not None) + (0 if self.B <= hb.XENT_STEP_MAX_ROWS else 1)
 
     # -- data -----------------------------------------------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -161,12 +161,18 @@ class DenseStackEngine:
     def _step_gpu(self, bi: int, fused: bool, scale: float):
         x, y = self._batch(bi)
         slot = self._slot(bi)
-        # (the counter's bump commutes with everything else in the step: nothing in it reads global_step)
-        hb.dense_step_begin(self.loss_sum[slot:slot + 1], self.correct[slot:slot + 1],
-                            self.global_step if fused else None)
-        logits = self._forward_gpu(x, self.a)
-        hb.softmax_xent(logits, y, dz=self.dz[-1], grad_scale=(1.0 if fused else scale) / self.B,
-                        loss_sum=self.loss_sum[slot:slot + 1], correct=self.correct[slot:slot + 1])
+        loss_slot, correct_slot = self.loss_sum[slot:slot + 1], self.correct[slot:slot + 1]
+        gs = self.global_step if fused else None
+        gscale = (1.0 if fused else scale) / self.B
+        if self.B <= hb.XENT_STEP_MAX_ROWS:
+            # one workgroup: loss and count stored in a fixed order, the step counter bumped in the same launch
+            logits = self._forward_gpu(x, self.a)
+            hb.softmax_xent_step(logits, y, self.dz[-1], gscale, loss_slot, correct_slot, gs)
+        else:
+            # (the counter's bump commutes with everything else in the step: nothing in it reads global_step)
+            hb.dense_step_begin(loss_slot, correct_slot, gs)
+            logits = self._forward_gpu(x, self.a)
+            hb.softmax_xent(logits, y, dz=self.dz[-1], grad_scale=gscale, loss_sum=loss_slot, correct=correct_slot)
         for i in range(self.L - 1, -1, -1):
             below = self.a[i - 1] if i > 0 else x
             if i > 0:       # before W_i changes: dz_{i-1} = (dz_i W_i^T) * act'(a_{i-1})

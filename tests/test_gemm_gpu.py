@@ -185,3 +185,24 @@ def test_colsum_tall_matrix_uses_row_segments():
     lr = torch.tensor([0.1], device=DEV)
     hb.colsum(z, out=b, sgd=True, lr=lr)
     torch.testing.assert_close(b, (b0.double() - 0.1 * z.double().sum(0)).float(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,C", [(100, 10), (1, 3), (1000, 37), (2048, 10)])
+def test_softmax_xent_step_one_workgroup_head(M, C):
+    z = _rand(M, C, scale=3.0, seed=31)
+    y = torch.zeros(M, C, device=DEV)
+    y[torch.arange(M), torch.randint(0, C, (M,), generator=torch.Generator().manual_seed(32))] = 1.0
+    zd = z.double().requires_grad_(True)
+    rows = -(y.double() * torch.log_softmax(zd, 1)).sum(1)
+    rows.sum().backward()
+    dz = torch.empty_like(z)
+    loss = torch.full((1,), 123.0, device=DEV)                    # stored, not accumulated: old contents do not matter
+    correct = torch.full((1,), 77, dtype=torch.int32, device=DEV)
+    gs = torch.tensor([41.0], device=DEV)
+    hb.softmax_xent_step(z, y, dz, 1.0 / M, loss, correct, gs)
+    torch.testing.assert_close(loss[0], rows.sum().detach().float(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dz, (zd.grad / M).float(), rtol=1e-4, atol=1e-6)
+    assert int(correct.item()) == int((z.argmax(1) == y.argmax(1)).sum().item()) and float(gs) == 42.0
+    again = torch.empty(1, device=DEV)
+    hb.softmax_xent_step(z, y, dz, 1.0 / M, again, correct, None)
+    assert torch.equal(again, loss) and float(gs) == 42.0         # a fixed order of additions; no counter given, none bumped
