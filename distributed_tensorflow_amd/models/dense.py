@@ -17,8 +17,9 @@ every launch a kernel of ``csrc/gemm.hip``:
             tfdist_between.py:65-66) or a plain store into a gradient tensor (parameter-server modes), and the bias
             gradient as a column sum with the same two endings.
 
-4 L launches per fused step (L = number of layers, with biases; one more, which clears the step's loss / accuracy
-accumulators and bumps the step counter, for batches too tall for the one-workgroup head), all on the current stream, captured into hipGraph chunks by
+4 L + 1 launches per fused step (L = number of layers, with biases; one of them clears the step's loss / accuracy
+accumulators and bumps the step counter; batches of up to 16 rows fold it into a one-workgroup head), all on the current
+stream, captured into hipGraph chunks by
 ``run_chunk`` when the mini-batches come from a resident set.  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
