@@ -199,6 +199,10 @@ int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float* B, float* 
 // out[n] = scale * sum_m z[m*ldz + n]  (mode DTF_EPI_NONE)  or  out[n] -= lr[0] * scale * sum  (mode DTF_EPI_SGD)
 int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out, int mode, float scale, const float* lr,
                void* stream);
+// Column sums of up to 16 matrices in one launch (HOST arrays of device addresses and shapes; no row segments: meant for
+// batches of up to a few thousand rows).
+int dtf_colsum_multi(int count, const uint64_t* z, const int64_t* ldz, const int32_t* M, const int32_t* N,
+                     const uint64_t* out, int mode, float scale, const float* lr, void* stream);
 // The head of a training step in one launch (M <= 8192 rows, one workgroup): *loss_out = sum of the row losses,
 // *correct_out = rows classified like their labels (both STORED, in a fixed order of additions), dz as above,
 // *global_step += 1 (each output may be null).

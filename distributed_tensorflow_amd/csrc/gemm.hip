@@ -567,6 +567,51 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+// The same for several matrices in ONE launch (the bias gradients of all layers at the end of a backward pass): block
+// b belongs to the matrix whose range of column blocks contains it.
+struct ColsumTable {
+  const float* z[16];
+  float* out[16];
+  long ldz[16];
+  int M[16], N[16];
+  int first_block[17];      // column blocks of matrix t: [first_block[t], first_block[t + 1])
+  int count;
+};
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumTable t, int mode, float scale, const float* lr) {
+  __shared__ float part[16][64];
+  int which = 0;
+#pragma unroll 1
+  while (which + 1 < t.count && (int)blockIdx.x >= t.first_block[which + 1]) ++which;
+  const float* __restrict__ z = t.z[which];
+  const long ldz = t.ldz[which];
+  const int M = t.M[which], N = t.N[which];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = ((int)blockIdx.x - t.first_block[which]) * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int m = wave;
+    for (; m + 48 < M; m += 64) {
+      s0 += z[(long)m * ldz + n];
+      s1 += z[(long)(m + 16) * ldz + n];
+      s2 += z[(long)(m + 32) * ldz + n];
+      s3 += z[(long)(m + 48) * ldz + n];
+    }
+    for (; m < M; m += 16) s0 += z[(long)m * ldz + n];
+  }
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += part[w][lane];
+    float* out = t.out[which];
+    if (mode == DTF_EPI_SGD)
+      out[n] -= lr[0] * scale * s;
+    else
+      out[n] = scale * s;
+  }
+}
+
 // ---- start of a training step: the step's loss / accuracy accumulators cleared, the step counter bumped (one thread) ---
 __global__ void dense_step_begin_kernel(float* loss_sum, int* correct, float* global_step) {
   if (loss_sum != nullptr) *loss_sum = 0.f;
@@ -739,6 +784,31 @@ extern "C" int dtf_colsum(const float* z, int64_t ldz, int M, int N, float* out,
     return DTF_ERR_LAUNCH;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, segments), dim3(1024), 0, static_cast<hipStream_t>(stream), z,
                      (long)ldz, M, N, out, mode, scale, lr);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_colsum_multi(int count, const uint64_t* z, const int64_t* ldz, const int32_t* M, const int32_t* N,
+                                const uint64_t* out, int mode, float scale, const float* lr, void* stream) {
+  if (count < 1 || count > 16 || z == nullptr || ldz == nullptr || M == nullptr || N == nullptr || out == nullptr)
+    return DTF_ERR_SHAPE;
+  if (mode != DTF_EPI_NONE && mode != DTF_EPI_SGD) return DTF_ERR_SHAPE;
+  if (mode == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
+  ColsumTable t{};
+  t.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (z[i] == 0 || out[i] == 0) return DTF_ERR_NULL;
+    if (M[i] < 1 || N[i] < 1 || ldz[i] < N[i]) return DTF_ERR_SHAPE;
+    t.z[i] = reinterpret_cast<const float*>(z[i]);
+    t.out[i] = reinterpret_cast<float*>(out[i]);
+    t.ldz[i] = ldz[i];
+    t.M[i] = M[i];
+    t.N[i] = N[i];
+    t.first_block[i] = blocks;
+    blocks += (N[i] + 63) / 64;
+  }
+  t.first_block[count] = blocks;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), t, mode, scale, lr);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

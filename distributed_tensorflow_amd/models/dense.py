@@ -17,9 +17,10 @@ every launch a kernel of ``csrc/gemm.hip``:
             tfdist_between.py:65-66) or a plain store into a gradient tensor (parameter-server modes), and the bias
             gradient as a column sum with the same two endings.
 
-4 L + 1 launches per fused step (L = number of layers, with biases; one of them clears the step's loss / accuracy
-accumulators and bumps the step counter; batches of up to 16 rows fold it into a one-workgroup head), all on the current
-stream, captured into hipGraph chunks by
+3 L + 2 launches per fused step of L layers: one that clears the step's loss / accuracy accumulators and bumps the step
+counter (batches of up to 16 rows fold it into a one-workgroup head), L forward GEMMs, the head, L - 1 input-gradient and
+L weight-gradient GEMMs, and ONE column-sum launch for the bias gradients of all layers (batches beyond 4096 rows: one per
+layer, with row segments), all on the current stream, captured into hipGraph chunks by
 ``run_chunk`` when the mini-batches come from a resident set.  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
@@ -108,6 +109,7 @@ class DenseStackEngine:
         self._host_cursor = 0
         self._graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
         self._eval_bufs: Dict[int, list] = {}
+        self._colsum_plans: Dict[str, object] = {}
         # K-split workspace of this engine's GEMMs (a batch-100 layer has 26 tiles for 256 CUs): 34 MB, one per engine,
         # so two engines on two streams never share counters
         self._ws = hb.gemm_workspace(dev) if self.on_gpu else None
@@ -116,7 +118,8 @@ class DenseStackEngine:
     def launches_per_step(self) -> int:
         """Accumulator reset + step counter, L forward GEMMs, the head, L - 1 input gradients, L weight and L bias
         gradients (biases that exist)."""
-        return 3 * self.L + sum(1 for b in self.b if b is not None) + (0 if self.B <= hb.XENT_STEP_MAX_ROWS else 1)
+        biases = sum(1 for b in self.b if b is not None)
+        return 3 * self.L + (0 if self.B <= hb.XENT_STEP_MAX_ROWS else 1) + (min(1, biases) if self.B <= 4096 else biases)
 
     # -- data -----------------------------------------------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -182,13 +185,26 @@ class DenseStackEngine:
             if fused:
                 hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.W[i], epi=hb.EPI_SGD, lr=self.lr, scale=1.0,
                         workspace=self._ws)
-                if self.b[i] is not None:
-                    hb.colsum(self.dz[i], out=self.b[i], sgd=True, lr=self.lr)
             else:
-                gw, gb = self.g[i]
-                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=gw, workspace=self._ws)
-                if self.b[i] is not None:
-                    hb.colsum(self.dz[i], out=gb)
+                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.g[i][0], workspace=self._ws)
+        self._bias_gradients(fused)
+
+    def _bias_gradients(self, fused: bool):
+        """Column sums of every layer's dz into the biases (``b -= lr * sum``) or the bias-gradient tensors: ONE launch
+        at the end of the backward pass (every dz is still in place); batches beyond 4096 rows take a launch per layer,
+        whose row segments keep the tall sums parallel."""
+        pairs = [(self.dz[i], self.b[i] if fused else self.g[i][1]) for i in range(self.L) if self.b[i] is not None]
+        if not pairs:
+            return
+        if self.B > 4096 or len(pairs) > 16:
+            for z, out in pairs:
+                hb.colsum(z, out=out, sgd=fused, lr=self.lr if fused else None)
+            return
+        key = "fused" if fused else "grad"
+        plan = self._colsum_plans.get(key)
+        if plan is None:
+            plan = self._colsum_plans[key] = hb.ColsumPlan(pairs)
+        hb.colsum_multi(plan, sgd=fused, lr=self.lr if fused else None)
 
     def _step_cpu(self, bi: int, fused: bool, scale: float):
         x, y = self._batch(bi)

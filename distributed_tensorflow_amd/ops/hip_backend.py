@@ -147,6 +147,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_colsum.argtypes = [vp, i64, i32, i32, vp, i32, f32, vp, vp]
     lib.dtf_softmax_xent.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]
     lib.dtf_dense_step_begin.argtypes = [vp, vp, vp, vp]
+    lib.dtf_colsum_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, f32, vp, vp]
+    lib.dtf_colsum_multi.restype = C.c_int
     lib.dtf_softmax_xent_step.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]
     for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent", "dtf_dense_step_begin", "dtf_softmax_xent_step"):
         getattr(lib, name).restype = C.c_int
@@ -376,6 +378,36 @@ def colsum(z, out: Optional[torch.Tensor] = None, *, sgd: bool = False, lr: Opti
     _check(lib.dtf_colsum(_ptr(z), z.stride(0), M, N, _ptr(out), EPI_SGD if sgd else EPI_NONE, float(scale), _ptr(lr),
                           _stream()), "dtf_colsum")
     return out
+
+
+class ColsumPlan:
+    """Column sums of several matrices in ONE launch (``colsum_multi``): the host arrays of addresses and shapes are
+    built once for a fixed set of tensors (the dz / bias pairs of an engine)."""
+
+    def __init__(self, pairs):
+        pairs = list(pairs)
+        if not 1 <= len(pairs) <= 16:
+            raise HipKernelError("colsum_multi: 1 to 16 matrices")
+        for z, out in pairs:
+            _f32_2d(z, "z")
+            if _f32c(out, "out").numel() != z.shape[1] or out.device != z.device:
+                raise HipKernelError("colsum_multi: one output element per column")
+        n = len(pairs)
+        self.count = n
+        self.keep = pairs
+        self.z = (C.c_uint64 * n)(*[z.data_ptr() for z, _ in pairs])
+        self.out = (C.c_uint64 * n)(*[o.data_ptr() for _, o in pairs])
+        self.ldz = (C.c_int64 * n)(*[z.stride(0) for z, _ in pairs])
+        self.M = (C.c_int32 * n)(*[z.shape[0] for z, _ in pairs])
+        self.N = (C.c_int32 * n)(*[z.shape[1] for z, _ in pairs])
+
+
+def colsum_multi(plan: ColsumPlan, *, sgd: bool = False, lr: Optional[torch.Tensor] = None, scale: float = 1.0):
+    """``out_t = scale * z_t.sum(0)`` (or ``out_t -= lr * scale * z_t.sum(0)`` with ``sgd``) for every pair of the plan."""
+    if sgd and (lr is None or _f32c(lr, "lr").numel() != 1):
+        raise HipKernelError("colsum_multi: the SGD form needs a one-element device learning rate")
+    _check(require().dtf_colsum_multi(plan.count, plan.z, plan.ldz, plan.M, plan.N, plan.out, EPI_SGD if sgd else EPI_NONE,
+                                      float(scale), _ptr(lr), _stream()), "dtf_colsum_multi")
 
 
 def softmax_xent(logits, labels, *, dz: Optional[torch.Tensor] = None, grad_scale: float = 1.0,

@@ -206,3 +206,17 @@ def test_softmax_xent_step_one_workgroup_head(M, C):
     again = torch.empty(1, device=DEV)
     hb.softmax_xent_step(z, y, dz, 1.0 / M, again, correct, None)
     assert torch.equal(again, loss) and float(gs) == 42.0         # a fixed order of additions; no counter given, none bumped
+
+
+def test_colsum_multi_one_launch_for_several_matrices():
+    zs = [_rand(100, n, scale=0.1, seed=40 + n) for n in (10, 300, 64, 1)]
+    outs = [_rand(n, seed=50 + n) for n in (10, 300, 64, 1)]
+    before = [o.clone() for o in outs]
+    plan = hb.ColsumPlan(list(zip(zs, outs)))
+    lr = torch.tensor([0.2], device=DEV)
+    hb.colsum_multi(plan, sgd=True, lr=lr, scale=0.5)
+    for z, o, o0 in zip(zs, outs, before):
+        torch.testing.assert_close(o, (o0.double() - 0.1 * z.double().sum(0)).float(), rtol=1e-5, atol=1e-6)
+    hb.colsum_multi(plan, scale=2.0)
+    for z, o in zip(zs, outs):
+        torch.testing.assert_close(o, (2.0 * z.double().sum(0)).float(), rtol=1e-5, atol=1e-6)
