@@ -169,3 +169,34 @@ def test_data_parallel_trainer_gpu_streams_match_cpu_run():
     assert runs[0][1] == runs[1][1] == 15
     torch.testing.assert_close(runs[1][0], runs[0][0], rtol=2e-4, atol=2e-5)
     assert abs(runs[0][2] - runs[1][2]) < 1e-3
+
+
+def test_stack_without_biases_and_with_tall_batch():
+    """No bias anywhere (no column-sum launch), and a batch beyond the one-launch column sum's 4096 rows."""
+    dims, acts = (96, 80, 12), ("tanh",)
+    Ws, _, gen = _stack(dims)
+    for B in (64, 4200):
+        x = torch.rand(B, dims[0], generator=gen)
+        y = torch.eye(dims[-1])[torch.randint(0, dims[-1], (B,), generator=gen)]
+        for with_bias in (False, True):
+            W = [w.clone() for w in Ws]
+            bs = [torch.zeros(n) for n in dims[1:]]
+            eng = DenseStackEngine([w.to(DEV) for w in W], [b.to(DEV) for b in bs] if with_bias else [None, None], acts,
+                                   batch=B, lr=0.3)
+            eng.bind_data(x.to(DEV), y.to(DEV))
+            eng.run_chunk(2, use_graph=False)
+            if with_bias:
+                for _ in range(2):
+                    _oracle_step(W, bs, acts, x, y, 0.3)
+                for b, be in zip(bs, eng.b):
+                    torch.testing.assert_close(be.cpu(), b, rtol=2e-4, atol=2e-5)
+            else:
+                Wd = [w.double() for w in W]
+                for _ in range(2):
+                    leaves = [w.clone().requires_grad_(True) for w in Wd]
+                    h = torch.tanh(x.double() @ leaves[0]) @ leaves[1]
+                    (-(y.double() * torch.log_softmax(h, 1)).sum(1).mean()).backward()
+                    Wd = [(w - 0.3 * w.grad).detach() for w in leaves]
+                W = [w.float() for w in Wd]
+            for w, we in zip(W, eng.W):
+                torch.testing.assert_close(we.cpu(), w, rtol=2e-4, atol=2e-5)

@@ -220,3 +220,24 @@ def test_colsum_multi_one_launch_for_several_matrices():
     hb.colsum_multi(plan, scale=2.0)
     for z, o in zip(zs, outs):
         torch.testing.assert_close(o, (2.0 * z.double().sum(0)).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_workspace_too_small_falls_back_to_one_workgroup_per_tile():
+    a, b, want = _operands(hb.GEMM_NN, 100, 256, 2048, seed=61)
+    small = torch.zeros(1024 + 3 * 64 * 64, dtype=torch.float32, device=DEV)      # room for less than two ranges of 8 tiles
+    got = hb.gemm(hb.GEMM_NN, a, b, workspace=small)
+    torch.testing.assert_close(got, want.float(), rtol=2e-5, atol=2e-5 * 2048 ** 0.5)
+    assert int(small[:1024].view(torch.int32).abs().sum()) == 0
+    tiny = torch.zeros(16, dtype=torch.float32, device=DEV)                       # not even the counters: ignored
+    torch.testing.assert_close(hb.gemm(hb.GEMM_NN, a, b, workspace=tiny), want.float(), rtol=2e-5, atol=2e-5 * 2048 ** 0.5)
+
+
+def test_gemm_refuses_leading_dimensions_beyond_its_32_bit_offsets():
+    # a row stride of 5 M floats: 128 rows of a tile span more than 2 GB
+    wide = torch.empty(0, device=DEV)
+    try:
+        wide = torch.empty((130, 5_000_000), dtype=torch.float32, device=DEV)     # 2.6 GB
+    except RuntimeError:
+        pytest.skip("no room for the 2.6 GB operand")
+    with pytest.raises(hb.HipKernelError, match="unsupported"):
+        hb.gemm(hb.GEMM_NT, wide[:, :64], wide[:, 64:128])
