@@ -556,6 +556,15 @@ def run_benchmark(args) -> Optional[dict]:
 
                 store.wait(["dtf_bench_ingraph_done"], datetime.timedelta(seconds=900))
 
+    # ---- the same graph with wider / more layers on the dense-layer kernels (one GPU; never part of the headline) -------
+    if (n == 1 and not use_cpu and not ingraph_only and args.mode in (None, "auto", "single")
+            and os.environ.get("DTF_BENCH_DENSE", "1") != "0" and within_budget()):
+        wd.stage("dense stacks")
+        try:
+            result_extra["dense_stacks"] = _measure_dense_stacks(device)
+        except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
+            result_extra["dense_stacks"] = {"error": f"{type(e).__name__}: {e}"}
+
     result = None
     if rank == 0:
         if ingraph_only:
@@ -615,6 +624,36 @@ def _result(n, steps, warmup, elapsed, parallelism, source, use_cpu, device, ran
                         else "run_steps(%d)" % steps,
     }
     out.update(extra)
+    return out
+
+
+def _measure_dense_stacks(device) -> dict:
+    """Training steps of fully connected stacks other than the reference's network (models/dense.py on csrc/gemm.hip):
+    fp32, synthetic data, hipGraph chunks; TFLOP/s counts the step's GEMMs (forward, input and weight gradients)."""
+    from .models.dense import DenseStackEngine
+
+    out = {"note": "not the reference's workload: the same graph with wider layers, every launch a hand-written kernel"}
+    for dims, batch, steps in (((784, 1024, 1024, 10), 100, 160), ((784, 4096, 4096, 10), 4096, 24)):
+        gen = torch.Generator().manual_seed(0)
+        Ws = [(torch.randn(dims[i], dims[i + 1], generator=gen) / dims[i] ** 0.5).to(device) for i in range(len(dims) - 1)]
+        bs = [torch.zeros(dims[i + 1], device=device) for i in range(len(dims) - 1)]
+        nb = 8
+        x = torch.rand(nb * batch, dims[0], generator=gen).to(device)
+        y = torch.eye(dims[-1])[torch.randint(0, dims[-1], (nb * batch,), generator=gen)].to(device)
+        eng = DenseStackEngine(Ws, bs, ["relu"] * (len(dims) - 2), batch=batch, lr=0.01)
+        eng.bind_data(x, y)
+        eng.run_chunk(nb)                      # captures the chunk graph
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps // nb):
+            eng.run_chunk(nb)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / (steps // nb * nb)
+        flop = 6.0 * batch * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) - 2.0 * batch * dims[0] * dims[1]
+        out["-".join(map(str, dims)) + f" batch {batch}"] = {
+            "ms_per_step": round(1000.0 * dt, 5), "samples_per_s": round(batch / dt, 1),
+            "gemm_tflops": round(flop / dt / 1e12, 1), "launches_per_step": eng.launches_per_step, "dtype": "fp32"}
+        del eng, Ws, bs, x, y
     return out
 
 
