@@ -65,11 +65,14 @@ class Watchdog:
         self._result = None
         self._emitted = False
         self._stage = "start"
+        self._stage_deadline = None
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
 
-    def stage(self, name: str):
+    def stage(self, name: str, limit_s: Optional[float] = None):
+        """Names what runs now; ``limit_s`` bounds THIS stage (an optional one that may hang in a collective)."""
         self._stage = name
+        self._stage_deadline = None if limit_s is None else time.monotonic() + limit_s
 
     def hold(self, result: Optional[dict]):
         with self._lock:
@@ -87,7 +90,7 @@ class Watchdog:
             return result
 
     def _run(self):
-        while time.monotonic() < self.deadline:
+        while time.monotonic() < min(self.deadline, self._stage_deadline or self.deadline):
             time.sleep(0.25)
             if self._emitted:
                 return
@@ -97,6 +100,12 @@ class Watchdog:
             self._emitted = True
             res = self._result
         print(f"[bench rank {self.rank}] wall-time limit reached in stage '{self._stage}'", file=sys.stderr, flush=True)
+        try:                        # where every thread of this rank stands: the one diagnosis a hang leaves behind
+            import faulthandler
+
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:  # noqa: BLE001
+            pass
         if self.rank == 0 and res is not None:
             res["truncated_at_stage"] = self._stage
             print(json.dumps(res), flush=True)
@@ -565,6 +574,21 @@ def run_benchmark(args) -> Optional[dict]:
         except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
             result_extra["dense_stacks"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- data-parallel steps of a wide stack: megabytes of gradients per step, bucketed all-reduce under the backward ----
+    want_dense_dp = (distributed and not ingraph_only and args.mode in (None, "auto")
+                     and os.environ.get("DTF_BENCH_DENSE", "1") != "0")
+    if want_dense_dp and within_budget():
+        if rank == 0 and best is not None:      # what is printed should this stage hang in a collective
+            wd.hold(_result(n, steps, warmup, elapsed, parallelism, mnist.source, use_cpu, device, ranks_seen, result_extra))
+        wd.stage("dense stack, data parallel", limit_s=float(os.environ.get("DTF_BENCH_DENSE_DP_S", "120")))
+        try:
+            rep = _measure_dense_dp(device, rank, world)
+        except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
+            rep = {"error": f"{type(e).__name__}: {e}"}
+        if not agree("error" not in rep):
+            rep = {"error": rep.get("error", "failed on another rank")}
+        result_extra["dense_dp"] = rep
+
     result = None
     if rank == 0:
         if ingraph_only:
@@ -654,6 +678,51 @@ def _measure_dense_stacks(device) -> dict:
             "ms_per_step": round(1000.0 * dt, 5), "samples_per_s": round(batch / dt, 1),
             "gemm_tflops": round(flop / dt / 1e12, 1), "launches_per_step": eng.launches_per_step, "dtype": "fp32"}
         del eng, Ws, bs, x, y
+    return out
+
+
+def _measure_dense_dp(device, rank: int, world: int) -> dict:
+    """Synchronous data-parallel steps of a 784-4096-4096-10 stack (parallel/dense_trainer.py): 80 MB of gradients per
+    step in buckets, each all-reduced on a side stream under the backward of the layers below.  Every rank calls this at
+    the same place; the same steps without collectives say what the overlap has to hide."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from .data import DeviceDataset
+    from .parallel.dense_trainer import DenseDataParallelTrainer
+
+    dims, batch, steps, warm = (784, 4096, 4096, 10), int(os.environ.get("DTF_BENCH_DENSE_DP_BATCH", "4096")), 16, 3
+    if device.type == "cpu":        # CPU rehearsal of the flow (gloo): a stack small enough for a test
+        dims, batch, steps, warm = (784, 64, 64, 10), 32, 4, 1
+    rng = np.random.RandomState(100 + rank)
+    rows = 4 * batch
+    images = rng.rand(rows, dims[0]).astype(np.float32)
+    onehot = np.eye(dims[-1], dtype=np.float32)[rng.randint(0, dims[-1], rows)]
+    ds = DeviceDataset(images, onehot, device, batch, seed=rank)
+    out = {"model": "-".join(map(str, dims)), "batch_per_rank": batch, "ranks": world, "steps": steps, "warmup": warm,
+           "dtype": "fp32", "note": "not the reference's workload: its update rule on a model whose gradients are megabytes"}
+    for tag, w in (("with_collectives", world), ("compute_only", 1)):
+        tr = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, batch, 0.01, device, rank, w, seed=1)
+        tr.run_steps(warm)
+        _sync(device, True)
+        t0 = time.perf_counter()
+        tr.run_steps(steps)
+        _sync(device, True)
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        out[tag] = {"ms_per_step": round(1000.0 * dt / steps, 4), "samples_per_s": round(world * batch * steps / dt, 1)}
+        if tag == "with_collectives":
+            out["parallelism"] = tr.describe()
+            out["global_step"] = tr.global_step_value()
+            ck = torch.tensor([tr.replica_checksum()], dtype=torch.float64, device=device)
+            lo, hi = ck.clone(), ck.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            out["replicas_identical"] = bool(float(lo.item()) == float(hi.item()))
+            out["last_loss"] = round(tr.last_loss(), 4)
+        del tr
+    out["exposed_collective_ms_per_step"] = round(out["with_collectives"]["ms_per_step"] - out["compute_only"]["ms_per_step"], 4)
     return out
 
 

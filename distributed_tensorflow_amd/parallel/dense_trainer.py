@@ -168,12 +168,20 @@ class DenseDataParallelTrainer:
                 start = end
         self._closes_bucket = last_layer              # layer index -> bucket it completes
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # GPU ranks over gloo (several ranks sharing one GPU in a rehearsal: RCCL refuses that) reduce through the host:
+        # gloo's own handling of device tensors was seen to hang on a 64 MB bucket issued from a side stream
+        self._host_reduce = False
+        self._reduce = self.world > 1 or group is not None      # an explicit group is used even by a lone rank
+        if self._reduce and self.device.type == "cuda":
+            import torch.distributed as dist
+
+            self._host_reduce = dist.get_backend(group) == "gloo"
 
     def describe(self) -> str:
         mb = [round((b - a) * 4 / (1 << 20), 2) for a, b in self.buckets]
         return (f"dense stack {'-'.join(str(n) for n in self.engine.dims)} dp{self.world}: all-reduce of {len(mb)} "
                 f"gradient bucket(s) {mb} MB on a side stream under the backward of the layers below, SGD on the reduced "
-                f"range, {'RCCL' if self.device.type == 'cuda' else 'gloo'}")
+                f"range, {'RCCL' if self.device.type == 'cuda' and not self._host_reduce else 'gloo'}")
 
     # -- one step -------------------------------------------------------------------------------------------------
     def _reduce_apply(self, k: int):
@@ -181,7 +189,11 @@ class DenseDataParallelTrainer:
 
         a, b = self.buckets[k]
         g = self.grads[a:b]
-        if self.world > 1:
+        if self._reduce and self._host_reduce:
+            h = g.cpu()
+            dist.all_reduce(h, group=self.group)
+            g.copy_(h)
+        elif self._reduce:
             dist.all_reduce(g, group=self.group)
         if self.device.type == "cuda":
             self.hb.sgd_apply_(self.params[a:b], g, self.lr, 1.0 / self.world)

@@ -53,6 +53,9 @@ def test_two_ranks_over_gloo_report_the_aggregate(mode):
         a = r["async_mode"]                           # and the asynchronous mode next to it, on the same data set
         assert a["global_step"] == 2 * (a["steps"] + a["warmup"]) and a["every_push_counted"] is True
         assert "send/recv" in a["parallelism"] and a["value"] > 0
+        d = r["dense_dp"]                             # a stack with bucketed gradient all-reduces, same two ranks
+        assert d["replicas_identical"] is True and d["ranks"] == 2 and d["global_step"] == d["steps"] + d["warmup"]
+        assert d["with_collectives"]["samples_per_s"] > 0 and d["compute_only"]["ms_per_step"] > 0
     else:                 # asynchronous parameter servers: every worker's gradient is its own update
         assert r["global_step"] == 2 * 24 and "send/recv" in r["config"]["parallelism"]
 
@@ -101,3 +104,6 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     assert set(doc["async_modes"]) == {"xgmi_async", "async_rccl"} and "one-sided" in doc["async_modes"]["xgmi_async"]["parallelism"]
     ig = doc["ingraph_mode"]                                # one client, towers sharing the GPU in this rehearsal
     assert ig["replicas_identical"] is True and ig["healthy"] is True and ig["host_calls_per_tower_per_chunk"] == 1
+    d = doc["dense_dp"]                                     # wide stack, gradient buckets reduced on a side stream
+    assert d["replicas_identical"] is True and d["global_step"] == d["steps"] + d["warmup"], d
+    assert d["model"] == "784-4096-4096-10" and d["with_collectives"]["samples_per_s"] > 0

@@ -171,6 +171,24 @@ def test_data_parallel_trainer_gpu_streams_match_cpu_run():
     assert abs(runs[0][2] - runs[1][2]) < 1e-3
 
 
+def test_data_parallel_trainer_reduces_through_rccl_on_its_side_stream():
+    """A one-rank RCCL communicator carries the bucket all-reduces (own process: the communicator is process-wide)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from cluster_utils import ROOT, free_ports
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dense_dp_rccl_worker.py"), str(free_ports(1)[0])],
+                       cwd=ROOT, capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert res["backend"] == "nccl" and "RCCL" in res["desc"] and res["buckets"] == 2
+    assert res["identical"] is True and res["global_step"] == 30           # parameters: bit for bit
+    assert abs(res["loss"] - res["loss_without"]) < 1e-6 and res["loss"] < 1.0  # (the loss is summed with atomics)
+
+
 def test_stack_without_biases_and_with_tall_batch():
     """No bias anywhere (no column-sum launch), and a batch beyond the one-launch column sum's 4096 rows."""
     dims, acts = (96, 80, 12), ("tanh",)
