@@ -107,3 +107,24 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     d = doc["dense_dp"]                                     # wide stack, gradient buckets reduced on a side stream
     assert d["replicas_identical"] is True and d["global_step"] == d["steps"] + d["warmup"], d
     assert d["model"] == "784-4096-4096-10" and d["with_collectives"]["samples_per_s"] > 0
+
+
+@pytest.mark.parametrize("held", [True, False])
+def test_watchdog_prints_the_held_result_when_a_stage_outlives_its_limit(held):
+    """The safety net of the multi-rank benchmark: a stage stuck in a collective ends the process with the complete
+    result that was registered before it (status 0), or with status 3 when there is none."""
+    code = ("import time\n"
+            "from distributed_tensorflow_amd.bench_support import Watchdog\n"
+            "wd = Watchdog(0, 300.0)\n"
+            + ("wd.hold({'metric': 'm', 'value': 1.5})\n" if held else "")
+            + "wd.stage('optional stage', limit_s=0.5)\n"
+            "time.sleep(30)\n"
+            "print('not reached')\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert "not reached" not in p.stdout and "wall-time limit reached in stage 'optional stage'" in p.stderr
+    assert 'File "<string>", line' in p.stderr                         # the main thread's stack is part of the diagnosis
+    if held:
+        assert p.returncode == 0
+        assert _json_line(p.stdout) == {"metric": "m", "value": 1.5, "truncated_at_stage": "optional stage"}
+    else:
+        assert p.returncode == 3 and p.stdout.strip() == ""
