@@ -8,5 +8,6 @@ timeout -k 10 300 python bench.py --gpus 1 > $out/bench_1gpu.json 2> $out/bench_
 python -c "import json; d=json.load(open('$out/bench_1gpu.json')); print(d['value'], d['ms_per_step'], d['sec_per_epoch'], d['vs_baseline'])"
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
+export DTF_BENCH_DENSE=0        # the trace is of the headline workload: no dense-stack stage
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -- python3 $root/bench.py --gpus 1 --steps 2200 --warmup 550 > $root/$out/trace.log 2>&1 || exit 1
 cd $root && find $out/trace -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-160
