@@ -20,12 +20,17 @@ every launch a kernel of ``csrc/gemm.hip``:
 3 L + 2 launches per fused step of L layers: one that clears the step's loss / accuracy accumulators and bumps the step
 counter (batches of up to 16 rows fold it into a one-workgroup head), L forward GEMMs, the head, L - 1 input-gradient and
 L weight-gradient GEMMs, and ONE column-sum launch for the bias gradients of all layers (batches beyond 4096 rows: one per
-layer, with row segments), all on the current stream, captured into hipGraph chunks by
-``run_chunk`` when the mini-batches come from a resident set.  On CPU tensors every method runs the same mathematics
+layer, with row segments), captured into hipGraph chunks by ``run_chunk`` when the mini-batches come from a resident set.
+All launches go to the current stream in that order.  (``DTF_DENSE_OVERLAP=1`` captures a step as a graph with BRANCHES
+instead — weight gradients next to the input-gradient GEMMs of the layers below them, bias sums next to the last weight
+gradients, the reset next to the forward pass — which shortens the critical path on paper and measured slower: edges
+between the streams of a hipGraph cost more than the launches they take off the chain.)  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -113,6 +118,11 @@ class DenseStackEngine:
         # K-split workspace of this engine's GEMMs (a batch-100 layer has 26 tiles for 256 CUs): 34 MB, one per engine,
         # so two engines on two streams never share counters
         self._ws = hb.gemm_workspace(dev) if self.on_gpu else None
+        # captured steps as graphs with branches: measured SLOWER than the chain (a dependency between two streams of a
+        # hipGraph costs more than the 1.6 us between two launches of one stream: 76 against 59 us per step of
+        # 784-100-10, 122 against 114 us of 784-1024-1024-10 at batch 100), so it is an option, not the default
+        self.overlap = os.environ.get("DTF_DENSE_OVERLAP", "0") == "1"
+        self._side = self._ws_side = None
 
     @property
     def launches_per_step(self) -> int:
@@ -162,32 +172,70 @@ class DenseStackEngine:
             h = acts_out[i]
         return h
 
+    def _branch_streams(self):
+        """Three side streams with a K-split workspace each (GEMMs that run at the same time must not share counters)."""
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self._ws_side = [hb.gemm_workspace(self.device) for _ in range(2)]
+        return self._side, self._ws_side
+
     def _step_gpu(self, bi: int, fused: bool, scale: float):
+        """With ``self.overlap`` a CAPTURED step is a graph with branches, not a chain: the weight gradient of layer i
+        needs only dz_i and the activations below, so it runs NEXT TO the input-gradient GEMMs of the layers below it
+        (after the one of its own layer, which still reads the old W_i), the bias column sums run next to the last
+        weight gradients, and the accumulator reset next to the forward pass.  Eager launches stay on one stream."""
         x, y = self._batch(bi)
         slot = self._slot(bi)
         loss_slot, correct_slot = self.loss_sum[slot:slot + 1], self.correct[slot:slot + 1]
         gs = self.global_step if fused else None
         gscale = (1.0 if fused else scale) / self.B
+        main = torch.cuda.current_stream(self.device)
+        branch = self.overlap and torch.cuda.is_current_stream_capturing()
+        side, ws_side = self._branch_streams() if branch else (None, None)
+
+        def fork(s):        # stream s goes on from this point of the main stream
+            ev = torch.cuda.Event()
+            ev.record(main)
+            s.wait_event(ev)
+
         if self.B <= hb.XENT_STEP_MAX_ROWS:
             # one workgroup: loss and count stored in a fixed order, the step counter bumped in the same launch
             logits = self._forward_gpu(x, self.a)
             hb.softmax_xent_step(logits, y, self.dz[-1], gscale, loss_slot, correct_slot, gs)
         else:
             # (the counter's bump commutes with everything else in the step: nothing in it reads global_step)
-            hb.dense_step_begin(loss_slot, correct_slot, gs)
+            if branch:
+                fork(side[2])
+                with torch.cuda.stream(side[2]):
+                    hb.dense_step_begin(loss_slot, correct_slot, gs)
+            else:
+                hb.dense_step_begin(loss_slot, correct_slot, gs)
             logits = self._forward_gpu(x, self.a)
+            if branch:
+                main.wait_stream(side[2])
             hb.softmax_xent(logits, y, dz=self.dz[-1], grad_scale=gscale, loss_sum=loss_slot, correct=correct_slot)
         for i in range(self.L - 1, -1, -1):
             below = self.a[i - 1] if i > 0 else x
             if i > 0:       # before W_i changes: dz_{i-1} = (dz_i W_i^T) * act'(a_{i-1})
                 hb.gemm(hb.GEMM_NT, self.dz[i], self.W[i], out=self.dz[i - 1], epi=hb.EPI_ACT_BWD,
                         act=self.acts[i - 1], aux=below, workspace=self._ws)
-            if fused:
-                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.W[i], epi=hb.EPI_SGD, lr=self.lr, scale=1.0,
-                        workspace=self._ws)
-            else:
-                hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.g[i][0], workspace=self._ws)
-        self._bias_gradients(fused)
+            if branch:
+                fork(side[i & 1])
+            with torch.cuda.stream(side[i & 1]) if branch else contextlib.nullcontext():
+                ws = ws_side[i & 1] if branch else self._ws
+                if fused:
+                    hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.W[i], epi=hb.EPI_SGD, lr=self.lr, scale=1.0,
+                            workspace=ws)
+                else:
+                    hb.gemm(hb.GEMM_TN, below, self.dz[i], out=self.g[i][0], workspace=ws)
+        if branch:
+            fork(side[2])
+            with torch.cuda.stream(side[2]):
+                self._bias_gradients(fused)
+            for s in side:
+                main.wait_stream(s)
+        else:
+            self._bias_gradients(fused)
 
     def _bias_gradients(self, fused: bool):
         """Column sums of every layer's dz into the biases (``b -= lr * sum``) or the bias-gradient tensors: ONE launch

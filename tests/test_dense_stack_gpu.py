@@ -53,7 +53,10 @@ def test_fused_steps_match_autograd(dims, acts, B):
     assert abs(acc - float((h.argmax(1) == y.argmax(1)).double().mean())) < 2.0 / x.shape[0]
 
 
-def test_graph_chunks_equal_eager_steps():
+@pytest.mark.parametrize("branched", [False, True])
+def test_graph_chunks_equal_eager_steps(branched):
+    """``branched``: the captured step as a graph with side-stream branches (``DTF_DENSE_OVERLAP=1``; measured slower
+    than the chain, kept as an option) must be the same arithmetic."""
     dims, acts, B = (784, 256, 128, 10), ("relu", "relu"), 100
     Ws, bs, gen = _stack(dims)
     x = torch.rand(6 * B, dims[0], generator=gen).to(DEV)
@@ -63,6 +66,7 @@ def test_graph_chunks_equal_eager_steps():
         eng = DenseStackEngine([w.to(DEV) for w in Ws], [b.to(DEV) for b in bs], acts, batch=B, lr=0.1,
                                global_step=torch.zeros(1, device=DEV))
         eng.bind_data(x, y)
+        eng.overlap = branched
         for n in (4, 4, 4):             # 12 steps over a 6-batch epoch
             eng.run_chunk(n, use_graph=use_graph)
         engines.append(eng)
