@@ -8,3 +8,10 @@ for cfg in "tfdist_between.py 1 2 ipc" "tfdist_between.py 2 2 tcp" "tfdist_betwe
       --hidden=256,128 --activation=relu --lr=0.05 >> $out/results.jsonl 2>> $out/err.txt || { tail -30 $out/err.txt; exit 1; }
   tail -1 $out/results.jsonl | cut -c1-700
 done
+# the device-resident asynchronous worker of the same stack (hipGraph chunks of pull -> step -> push against the mapped shards)
+for cfg in "1 1" "1 2" "2 2"; do
+  set -- $cfg
+  timeout -k 10 240 python bench/run_cluster.py --script tfdist_between.py --ps $1 --workers $2 --transport ipc --epochs 5 --timeout 200 -- \
+      --hidden=256,128 --activation=relu --lr=0.05 --resident >> $out/results_resident.jsonl 2>> $out/err.txt || { tail -30 $out/err.txt; exit 1; }
+  tail -1 $out/results_resident.jsonl | cut -c1-700
+done

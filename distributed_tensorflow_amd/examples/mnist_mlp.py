@@ -283,10 +283,21 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
         if sync and is_chief:
             sv.start_queue_runners(sess, [chief_queue_runner])
         writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
-        if flags.resident and hidden_widths(flags) != (100,):
-            print("--resident against parameter servers is built for the reference's 784-100-10 network; "
+        if flags.resident and hidden_widths(flags) != (100,) and sync:
+            print("--resident with synchronous replicas is built for the reference's 784-100-10 network; "
                   "this stack runs one sess.run per batch on the dense-layer kernels", flush=True)
             result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
+        elif flags.resident and hidden_widths(flags) != (100,):
+            from ..data import DeviceDataset
+            from ..parallel.dense_trainer import PsDenseResidentTrainer
+
+            ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, flags.batch_size,
+                               seed=1000 + flags.task_index)
+            trainer = PsDenseResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)))
+            trainer.prepare(steps_hint=(ds.batches_per_epoch,))
+            print(trainer.describe(), flush=True)
+            result = run_resident_loop(trainer, mnist, flags, writer, begin_time)
+            trainer.close()
         elif flags.resident and sync:
             from ..data import DeviceDataset
             from ..parallel.ps_resident import PsSyncResidentTrainer

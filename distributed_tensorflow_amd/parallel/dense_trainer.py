@@ -265,3 +265,138 @@ class DenseDataParallelTrainer:
 
     def close(self):
         pass
+
+
+class PsDenseResidentTrainer:
+    """Device-resident asynchronous worker of a between-graph cluster for a fully connected stack of any depth — what
+    ``ps_resident.PsResidentTrainer`` is for the reference's network (tfdist_between.py:92-96 without the per-batch
+    feed, fetch and host round trips).  A step is GPU work only::
+
+        pull     every parameter-server shard -> the session's parameter slab   (device copies out of the mapped shards)
+        compute  ``DenseStackEngine.step_grad``: forward, head, backward, gradients into the session's gradient slab
+        push     ``p -= lr * g`` on every shard, written through the mapping; global_step += 1 on its owner shard
+
+    With the ipc transport (shards in the parameter-server tasks' HBM) and ``use_locking=False`` all of it is captured
+    into hipGraph chunks; several such worker processes replay their graphs against the same shards without waiting for
+    each other — the reference's lock-free asynchronous update (tfdist_between.py:65).  Other transports issue the same
+    steps eagerly.  Driver surface of the other resident trainers (``examples.mnist_mlp.run_resident_loop``)."""
+
+    name = "ps-dense-resident"
+
+    def __init__(self, sess, train_op, dataset, batch: int, chunk: int = 50, use_graph: bool = True):
+        plan = sess._plan(train_op)
+        d = plan.get("dense")
+        if d is None:
+            raise ValueError("the train op's loss is not a fully connected stack with a softmax cross-entropy head")
+        opt = train_op.attrs["optimizer"]
+        self.sess, self.store, self.ds = sess, sess.store, dataset
+        self.device = sess.device
+        self.chunk = max(1, int(chunk))
+        self.lr_value = float(opt.lr_value())
+        self.use_locking = bool(opt.use_locking)
+        self.bump_step = train_op.attrs["global_step"] is not None
+        capturable = (self.device.type == "cuda" and not self.use_locking
+                      and type(self.store).__name__ in ("IpcVariableStore", "LocalVariableStore"))
+        self.use_graph = bool(use_graph) and capturable
+        self.params, self.grads = sess.theta, sess.grad
+        view = lambda slab, v: None if v is None else sess.layout.view(slab, v.op_name)  # noqa: E731
+        self.engine = DenseStackEngine([view(self.params, W) for W, _ in d["layers"]],
+                                       [view(self.params, b) for _, b in d["layers"]], d["acts"], batch=int(batch),
+                                       lr=self.lr_value,
+                                       grads=[(view(self.grads, W), view(self.grads, b)) for W, b in d["layers"]])
+        self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self._bound_set = getattr(dataset, "active", 0)
+        self._graphs = {}
+        if self.device.type == "cuda":
+            # load every kernel of a step outside any capture without touching the shards: a pull, the gradient
+            # kernels, and a push with lr = 0 that does not count as a step
+            self.store.pull(self.params)
+            self.engine.step_grad(0, 1.0)
+            self.store.push_apply(self.grads, 0.0, False, bump_step=False)
+            if hasattr(self.store, "_lr"):
+                self.store._lr(self.lr_value)   # eagerly: a fill recorded into a graph runs only when THAT graph does
+            torch.cuda.synchronize(self.device)
+
+    def describe(self) -> str:
+        return ("between-graph async worker, device-resident, dense stack " + "-".join(str(n) for n in self.engine.dims)
+                + f": pull -> {self.engine.launches_per_step} launches -> one-sided SGD push ({type(self.store).__name__}, "
+                + ("hipGraph chunks of %d)" % self.chunk if self.use_graph else "eager)"))
+
+    def _schedule(self, cursor: int, n: int):
+        bpe, out = self.engine.batches_per_epoch, []
+        while n > 0:
+            k = min(n, self.chunk, bpe - cursor % bpe)
+            out.append(k)
+            cursor += k
+            n -= k
+        return out
+
+    def _one_step(self, bi: int):
+        self.store.pull(self.params)
+        self.engine.step_grad(bi, 1.0)
+        self.store.push_apply(self.grads, self.lr_value, self.use_locking, bump_step=self.bump_step)
+
+    def _graph(self, pos: int, n: int):
+        key = (pos, n, self._bound_set)
+        g = self._graphs.get(key)
+        if g is None:
+            # no warm-up replay: a step writes the shared shards, which cannot be rolled back
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for i in range(n):
+                    self._one_step(pos + i)
+            self._graphs[key] = g
+        return g
+
+    def _bind_active_set(self):
+        index = getattr(self.ds, "active", 0)
+        if index != self._bound_set:
+            x, y, _ = self.ds.set_tensors(index)
+            self.engine.bind_data(x, y)
+            self._bound_set = index
+
+    def prepare(self, steps_hint=()):
+        """Capture the chunk graphs of the hinted run_steps() calls for the data copy that is bound now; should the
+        runtime refuse to capture the mapped-shard operations, the steps are issued eagerly from then on."""
+        if not self.use_graph:
+            return
+        cursor, bpe = self.engine._host_cursor, self.engine.batches_per_epoch
+        try:
+            for n in steps_hint:
+                for k in self._schedule(cursor, n):
+                    self._graph(cursor % bpe, k)
+                    cursor += k
+        except Exception as e:  # noqa: BLE001
+            print(f"[ps-dense-resident] graph capture failed ({type(e).__name__}: {e}); issuing steps eagerly", flush=True)
+            self.use_graph = False
+            self._graphs.clear()
+
+    def run_steps(self, n: int):
+        bpe = self.engine.batches_per_epoch
+        for k in self._schedule(self.engine._host_cursor, n):
+            cur = self.engine._host_cursor
+            if cur % bpe == 0 and cur > 0:
+                self.ds.shuffle_epoch()
+            self._bind_active_set()
+            pos = cur % bpe
+            if self.use_graph:
+                self._graph(pos, k).replay()
+            else:
+                for i in range(k):
+                    self._one_step(pos + i)
+            self.engine.advance(k)
+        self.sess._gs_mirror = None         # the step counter moved behind the session's back
+
+    def last_loss(self) -> float:
+        return self.engine.last_loss()
+
+    def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
+        self.store.pull(self.params)
+        return self.engine.evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        return self.store.global_step()
+
+    def close(self):
+        self._graphs.clear()

@@ -191,6 +191,55 @@ def test_deep_graph_against_parameter_servers_async():
             s.stop()
 
 
+def test_resident_async_worker_of_a_deep_stack_against_two_ps_shards():
+    """PsDenseResidentTrainer (here on the CPU: eager pull -> step_grad -> push per step) against the fp64 autograd
+    oracle on the same batches; the trained values are on the parameter-server shards afterwards."""
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+    from distributed_tensorflow_amd.parallel.dense_trainer import PsDenseResidentTrainer
+
+    rng = np.random.RandomState(0)
+    protos = rng.rand(10, 784).astype(np.float32)
+    labels = rng.randint(0, 10, 600)
+    images = (protos[labels] + 0.3 * rng.rand(600, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    cd = cluster_dict(2, 1)
+    cluster = tf.train.ClusterSpec(cd)
+    cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=20000)
+    servers = [tf.train.Server(cluster, "ps", i, config=cfg) for i in range(2)]
+    worker = tf.train.Server(cluster, "worker", 0, config=cfg)
+    try:
+        g = tf.Graph()
+        with g.as_default():
+            with tf.device(tf.train.replica_device_setter(worker_device="/job:worker/task:0", cluster=cluster)):
+                m = build_model(0.05, "relu", hidden=(32, 16))
+        sv = tf.train.Supervisor(graph=g, is_chief=True, global_step=m.global_step, init_op=m.init_op)
+        sess = sv.prepare_or_wait_for_session(worker.target)
+        start = [sess.var_tensor(v).clone() for v in m.weights + m.biases]
+        ds = DeviceDataset(images, onehot, sess.device, 50, seed=3)
+        fed = [(ds.x_epoch[i * 50:(i + 1) * 50].clone(), ds.y_epoch[i * 50:(i + 1) * 50].clone()) for i in range(7)]
+        tr = PsDenseResidentTrainer(sess, m.train_op, ds, 50, chunk=3)
+        assert "784-32-16-10" in tr.describe() and "eager" in tr.describe()
+        tr.prepare(steps_hint=(7,))
+        tr.run_steps(7)
+        assert tr.global_step_value() == 7 and sess.store.global_step() == 7
+        sess._pull()
+        trained = [sess.var_tensor(v).clone() for v in m.weights + m.biases]
+        loss_tr = tr.last_loss()
+        tr.close()
+        sess.close()
+        sv.stop()
+    finally:
+        for s in servers + [worker]:
+            s.stop()
+    Ws, bs = [w.clone() for w in start[:3]], [b.clone() for b in start[3:]]
+    for x, y in fed:
+        want_loss = _oracle_step(Ws, bs, ("relu", "relu"), x, y, 0.05)[0]
+    for got, want in zip(trained, Ws + bs):
+        torch.testing.assert_close(got, want.view_as(got), rtol=1e-4, atol=1e-5)
+    assert abs(loss_tr - want_loss) < 1e-4
+
+
 def test_resident_trainer_steps_the_sessions_variables():
     from distributed_tensorflow_amd.data import DeviceDataset
     from distributed_tensorflow_amd.examples.mnist_mlp import build_model
@@ -223,6 +272,27 @@ def test_resident_trainer_steps_the_sessions_variables():
             _, step = sess.run([m.train_op, m.global_step], feed_dict={m.x: images[:50], m.y_: onehot[:50]})
             assert step == 30.0 and sess.dense_steps == 1
             tr.close()
+
+
+def test_between_graph_script_with_resident_workers_of_a_deeper_stack(tmp_path):
+    """tfdist_between.py --resident --hidden 48,24 on CPU tasks (tcp shards, eager steps): 1 ps + 2 workers."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.05", "--resident", "--hidden=48,24",
+            "--activation=relu", f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between.py", 1, 2, args, timeout=280)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    finals = []
+    for i in range(2):
+        out = res[f"worker{i}"][1]
+        assert "dense stack 784-48-24-10" in out and "eager" in out and out.rstrip().endswith("Done"), out[-2000:]
+        finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
+        costs = [float(c) for c in re.findall(r"Cost: ([\d.]+)", out)]
+        assert costs[-1] < costs[0]
+    assert 2 * 22 * 2 - 3 <= max(finals) <= 2 * 22 * 2         # both workers' pushes are updates of the shared step
 
 
 def test_tfsingle_script_with_hidden_layers(tmp_path):

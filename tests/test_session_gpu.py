@@ -140,6 +140,30 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
     assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
 
 
+@pytest.mark.parametrize("n_ps,n_w", [(2, 2)])
+def test_resident_async_workers_of_a_deeper_stack_replay_hipgraphs_against_ipc_shards(n_ps, n_w, tmp_path):
+    """tfdist_between.py --resident --hidden 64,32: chunks of pull -> dense-layer kernels -> one-sided SGD push, captured
+    per worker process, against shards in the ps tasks' HBM."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.05", "--transport=ipc", "--resident",
+            "--hidden=64,32", "--activation=relu", f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between.py", n_ps, n_w, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    finals, costs = [], []
+    for i in range(n_w):
+        out = res[f"worker{i}"][1]
+        assert "dense stack 784-64-32-10" in out and "hipGraph chunks" in out, out[-2000:]
+        assert out.rstrip().endswith("Done")
+        finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+    assert 2 * 22 * n_w - 3 * (n_w - 1) <= max(finals) <= 2 * 22 * n_w       # every push is an update (see above)
+    assert all(c[-1] < c[0] for c in costs)
+
+
 @pytest.mark.parametrize("n_ps,n_w,transport", [(1, 2, "ipc"), (2, 2, "tcp")])
 def test_resident_sync_workers_exchange_inside_the_backward_launch(n_ps, n_w, transport, tmp_path):
     """tfdist_between_sync.py --resident: a replica per worker process, gradients swapped through peer-mapped
