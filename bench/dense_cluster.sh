@@ -15,3 +15,10 @@ for cfg in "1 1" "1 2" "2 2"; do
       --hidden=256,128 --activation=relu --lr=0.05 --resident >> $out/results_resident.jsonl 2>> $out/err.txt || { tail -30 $out/err.txt; exit 1; }
   tail -1 $out/results_resident.jsonl | cut -c1-700
 done
+# synchronous replicas of the same stack, device-resident (gradient launches + one exchange kernel per step)
+for cfg in "1 2" "2 2" "1 4"; do
+  set -- $cfg
+  timeout -k 10 240 python bench/run_cluster.py --script tfdist_between_sync.py --ps $1 --workers $2 --transport ipc --epochs 5 --timeout 200 -- \
+      --hidden=256,128 --activation=relu --lr=0.05 --resident >> $out/results_resident.jsonl 2>> $out/err.txt || { tail -30 $out/err.txt; exit 1; }
+  tail -1 $out/results_resident.jsonl | cut -c1-900
+done

@@ -283,10 +283,25 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
         if sync and is_chief:
             sv.start_queue_runners(sess, [chief_queue_runner])
         writer = tf.summary.FileWriter(flags.logs_path, graph=tf.get_default_graph()) if flags.summaries else None
-        if flags.resident and hidden_widths(flags) != (100,) and sync:
-            print("--resident with synchronous replicas is built for the reference's 784-100-10 network; "
-                  "this stack runs one sess.run per batch on the dense-layer kernels", flush=True)
+        if flags.resident and hidden_widths(flags) != (100,) and sync and sess.device.type != "cuda":
+            print("--resident with synchronous replicas of a deeper stack needs GPU workers; "
+                  "this stack runs one sess.run per batch", flush=True)
             result = run_session_loop(sess, m, mnist, flags, writer, begin_time)
+        elif flags.resident and hidden_widths(flags) != (100,) and sync:
+            from ..data import DeviceDataset
+            from ..parallel.dense_trainer import PsDenseSyncResidentTrainer
+
+            ds = DeviceDataset(mnist.train.images, mnist.train.labels, sess.device, flags.batch_size,
+                               seed=1000 + flags.task_index)
+            trainer = PsDenseSyncResidentTrainer(sess, m.train_op, ds, flags.batch_size, chunk=min(50, int(flags.freq)))
+            trainer.prepare(steps_hint=(ds.batches_per_epoch,))
+            print(trainer.describe(), flush=True)
+            result = run_resident_loop(trainer, mnist, flags, writer, begin_time)
+            if not trainer.healthy():
+                raise RuntimeError("a replica never delivered its gradients: the synchronous run is void")
+            if is_chief:
+                trainer.publish()           # the PS shards hold the trained variables again
+            trainer.close()
         elif flags.resident and hidden_widths(flags) != (100,):
             from ..data import DeviceDataset
             from ..parallel.dense_trainer import PsDenseResidentTrainer

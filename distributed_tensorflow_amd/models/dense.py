@@ -149,6 +149,14 @@ class DenseStackEngine:
             self._graphs.clear()
         self.x, self.y, self.batches_per_epoch = x, y, bpe
 
+    def bind_grads(self, grads: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]]):
+        """Point ``step_grad`` at another set of gradient tensors (e.g. the two slots of a double-buffered exchange)."""
+        grads = [(gw, gb) for gw, gb in grads]
+        for i, (gw, gb) in enumerate(grads):
+            if gw.shape != self.W[i].shape or not gw.is_contiguous() or (self.b[i] is not None and gb is None):
+                raise ValueError(f"gradient tensors of layer {i} must be shaped like its parameters")
+        self.g = grads
+
     def set_lr(self, lr: float):
         self.lr.fill_(float(lr))
 
@@ -248,7 +256,7 @@ class DenseStackEngine:
             for z, out in pairs:
                 hb.colsum(z, out=out, sgd=fused, lr=self.lr if fused else None)
             return
-        key = "fused" if fused else "grad"
+        key = "fused" if fused else ("grad", pairs[0][1].data_ptr())     # (gradient tensors can be re-bound)
         plan = self._colsum_plans.get(key)
         if plan is None:
             plan = self._colsum_plans[key] = hb.ColsumPlan(pairs)

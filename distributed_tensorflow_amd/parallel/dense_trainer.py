@@ -400,3 +400,136 @@ class PsDenseResidentTrainer:
 
     def close(self):
         self._graphs.clear()
+
+
+class PsDenseSyncResidentTrainer:
+    """Synchronous replicas of a deeper stack started the reference's way (``tfdist_between_sync.py --resident --hidden
+    ...``), device-resident: ``SyncReplicasOptimizer(replicas_to_aggregate = total_num_replicas = number of workers)``
+    is one update per N worker batches with the mean of their gradients (tfdist_between_sync.py:65-68).  Every worker
+    task keeps a replica of the variables (pulled from the PS shards the chief initialised); a step is the stack's
+    gradient launches (``DenseStackEngine.step_grad`` scaled by 1 / N, into one of two gradient slabs that alternate
+    from step to step) and ONE exchange kernel that waits for every worker's slab of that step, sums them in rank order
+    through HIP-IPC mappings and applies SGD to the local replica (``xgmi.XgmiExchange``: a bounded grid, so any number
+    of workers can share a GPU).  The handles travel through the control store of ps task 0; the replicas stay
+    bit-identical; ``publish()`` copies the chief's replica back into the PS shards.  Workers must share a node."""
+
+    name = "ps-dense-sync-resident"
+
+    def __init__(self, sess, train_op, dataset, batch: int, chunk: int = 50, use_graph: bool = True,
+                 timeout_ms: int = 60000):
+        from ..optim import SyncReplicasOptimizer
+        from .xgmi import StoreGroup, XgmiExchange
+
+        plan = sess._plan(train_op)
+        d = plan.get("dense")
+        if d is None:
+            raise ValueError("the train op's loss is not a fully connected stack with a softmax cross-entropy head")
+        opt = train_op.attrs["optimizer"]
+        if not isinstance(opt, SyncReplicasOptimizer):
+            raise ValueError("PsDenseSyncResidentTrainer is for SyncReplicasOptimizer train ops")
+        self.sess, self.store, self.ds = sess, sess.store, dataset
+        self.device = sess.device
+        if self.device.type != "cuda":
+            raise RuntimeError("the device-resident synchronous tier needs GPU workers")
+        self.rank, self.world = sess.server.task_index, sess.server.num_workers
+        if opt.replicas_to_aggregate != self.world or opt.total_num_replicas != self.world:
+            raise ValueError("the resident synchronous tier aggregates every worker's gradient: "
+                             "replicas_to_aggregate and total_num_replicas must equal the number of workers")
+        self.chunk = max(1, int(chunk))
+        self.use_graph = bool(use_graph)
+        layout = sess.layout
+        if train_op.attrs["global_step"] is None or layout.var_range["global_step"][0] >= 4:
+            raise RuntimeError("global_step must live in the first 16 bytes of the slab")
+        self.params = sess.theta
+        self.store.pull(self.params)                 # every replica starts from the chief's initial values
+        torch.cuda.synchronize(self.device)
+        self.global_step = layout.view(self.params, "global_step").view(1)
+        view = lambda slab, v: None if v is None else layout.view(slab, v.op_name)  # noqa: E731
+        group = StoreGroup(sess.server.client("ps", 0), "dense-sync-resident", self.rank, self.world)
+        self.xg = XgmiExchange(self.rank, self.world, self.params.numel(), self.device, group=group,
+                               uncached_grads=True, timeout_ms=timeout_ms)
+        for g in self.xg.grads:                      # whatever no variable covers (step counter, padding) adds zero
+            g.zero_()
+        self._gsets = [[(view(g, W), view(g, b)) for W, b in d["layers"]] for g in self.xg.grads]
+        self.engine = DenseStackEngine([view(self.params, W) for W, _ in d["layers"]],
+                                       [view(self.params, b) for _, b in d["layers"]], d["acts"], batch=int(batch),
+                                       lr=float(opt.lr_value()), grads=self._gsets[0])
+        self.lr = self.engine.lr
+        self.engine.bind_data(dataset.x_epoch, dataset.y_epoch)
+        self._bound_set = getattr(dataset, "active", 0)
+        self._graphs = {}
+        self.engine.step_grad(0, 0.0)                # loads the kernels outside any capture (gradients of zero weight)
+        for g in self.xg.grads:
+            g.zero_()
+        torch.cuda.synchronize(self.device)
+
+    def describe(self) -> str:
+        return (f"between-graph sync worker {self.rank} of {self.world}, device-resident, dense stack "
+                + "-".join(str(n) for n in self.engine.dims) + f": replica per worker, {self.engine.launches_per_step} "
+                f"launches + one exchange kernel per step over peer-mapped HBM (mean of {self.world}, one update per "
+                f"{self.world} batches)" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
+
+    _schedule = PsDenseResidentTrainer._schedule
+    _bind_active_set = PsDenseResidentTrainer._bind_active_set
+
+    def _one_step(self, bi: int, slot: int):
+        self.engine.bind_grads(self._gsets[slot])
+        self.engine.step_grad(bi, 1.0 / self.world)
+        self.xg.apply(self.params, self.lr, slot, self.global_step)
+
+    def _graph(self, pos: int, n: int, parity: int):
+        key = (pos, n, parity, self._bound_set)
+        g = self._graphs.get(key)
+        if g is None:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for i in range(n):
+                    self._one_step(pos + i, (parity + i) & 1)
+            self._graphs[key] = g
+        return g
+
+    def prepare(self, steps_hint=()):
+        if not self.use_graph:
+            return
+        cursor, bpe = self.engine._host_cursor, self.engine.batches_per_epoch
+        for n in steps_hint:
+            for k in self._schedule(cursor, n):
+                self._graph(cursor % bpe, k, cursor & 1)
+                cursor += k
+
+    def run_steps(self, n: int):
+        bpe = self.engine.batches_per_epoch
+        for k in self._schedule(self.engine._host_cursor, n):
+            cur = self.engine._host_cursor
+            if cur % bpe == 0 and cur > 0:
+                self.ds.shuffle_epoch()
+            self._bind_active_set()
+            pos = cur % bpe
+            if self.use_graph:
+                self._graph(pos, k, cur & 1).replay()
+            else:
+                for i in range(k):
+                    self._one_step(pos + i, (cur + i) & 1)
+            self.engine.advance(k)
+        self.sess._gs_mirror = None
+
+    def last_loss(self) -> float:
+        return self.engine.last_loss()
+
+    def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
+        return self.engine.evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        return int(round(float(self.global_step.item())))
+
+    def healthy(self) -> bool:
+        return not self.xg.failed()
+
+    def publish(self):
+        """Copy this replica into the PS shards (chief: end of the run, before a checkpoint)."""
+        self.store.publish(self.params)
+
+    def close(self):
+        self._graphs.clear()
+        self.xg.close()

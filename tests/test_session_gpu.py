@@ -190,6 +190,32 @@ def test_resident_sync_workers_exchange_inside_the_backward_launch(n_ps, n_w, tr
     assert all(c[-1] < c[0] for c in costs)
 
 
+@pytest.mark.parametrize("n_ps,n_w,transport", [(1, 2, "ipc"), (2, 3, "tcp")])
+def test_resident_sync_workers_of_a_deeper_stack_stay_identical(n_ps, n_w, transport, tmp_path):
+    """tfdist_between_sync.py --resident --hidden 64,32: a replica per worker process, the stack's gradient launches and
+    one exchange kernel per step (sum over every worker's slab through HIP-IPC mappings), one update per n_w batches."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.05", f"--transport={transport}", "--resident",
+            "--hidden=64,32", "--activation=relu", f"--logs_path={tmp_path}"]
+    res = launch_script("tfdist_between_sync.py", n_ps, n_w, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    steps, costs, accs = [], [], []
+    for i in range(n_w):
+        out = res[f"worker{i}"][1]
+        assert "dense stack 784-64-32-10" in out and "one exchange kernel per step" in out and "hipGraph chunks" in out, out[-2000:]
+        assert out.rstrip().endswith("Done")
+        steps.append([int(v) for v in re.findall(r"Step: (\d+),", out)])
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+        accs.append(re.findall(r"Test-Accuracy: ([\d.]+)", out))
+    assert all(s == steps[0] for s in steps) and steps[0][-1] == 2 * 22     # one update per n_w batches, in lock step
+    assert all(a == accs[0] for a in accs) and len(accs[0]) == 2            # bit-identical replicas evaluate identically
+    assert all(c[-1] < c[0] for c in costs)
+
+
 @pytest.mark.timeout(300)
 def test_more_resident_sync_workers_than_one_gpu_can_keep_spinning_use_the_bounded_exchange(tmp_path):
     """1 ps + 4 synchronous workers, all on the one GPU (the reference's scenario 2 with more workers): their
