@@ -151,6 +151,114 @@ class InGraphTowers:
         return all(torch.equal(ref0, p.cpu()) for p in self.params[1:])
 
 
+class DenseInGraphTowers:
+    """In-graph replication of a fully connected stack of any depth (``tfdist.py --hidden 512,256``): the host loop of
+    :class:`InGraphTowers` around ``models.dense.DenseStackEngine`` towers.  Every tower holds a replica of the
+    variables in one flat slab ([global_step][W_1][b_1]...[W_L][b_L], every tensor on a 16-byte boundary) and a
+    gradient slab of the same layout; per step every tower computes its gradients scaled by 1 / N on its own device,
+    the N slabs are all-reduced (RCCL's single-process entry between distinct GPUs, a plain sum otherwise) and every
+    tower applies the same SGD launch, so the replicas stay bit-identical and ``global_step`` advances once."""
+
+    def __init__(self, devices: Sequence, images, labels, batch: int, lr: float, hidden: Sequence[int],
+                 act: str = "relu", seed: int = 1, data_seed: int = 0):
+        from ..models.dense import DenseStackEngine
+
+        self.devices = [torch.device(d) for d in devices]
+        self.n = len(self.devices)
+        if self.n < 1:
+            raise ValueError("need at least one tower")
+        dims = [int(images.shape[1])] + [int(h) for h in hidden] + [int(labels.shape[1])]
+        L = len(dims) - 1
+        pad4 = lambda k: (k + 3) // 4 * 4  # noqa: E731
+        ranges, off = [], 4                      # the first 16 bytes hold the step counter
+        for i in range(L):
+            w = (off, off + dims[i] * dims[i + 1])
+            off = pad4(w[1])
+            b = (off, off + dims[i + 1])
+            off = pad4(b[1])
+            ranges.append((w, b))
+        gen = torch.Generator().manual_seed(int(seed))
+        first = torch.zeros(off, dtype=torch.float32)
+        for i, (w, _) in enumerate(ranges):      # stddev 1 / sqrt(fan-in), biases zero (examples.mnist_mlp._build_deep_model)
+            first[w[0]:w[1]] = (torch.randn(dims[i], dims[i + 1], generator=gen) * dims[i] ** -0.5).reshape(-1)
+        self.params: List[torch.Tensor] = []
+        self.grads: List[torch.Tensor] = []
+        self.engines, self.datasets = [], []
+        for t, dev in enumerate(self.devices):
+            p, g = first.clone().to(dev), torch.zeros(off, dtype=torch.float32, device=dev)     # (own copy per tower)
+            views = lambda slab: [(slab[w[0]:w[1]].view(dims[i], dims[i + 1]), slab[b[0]:b[1]])  # noqa: E731
+                                  for i, (w, b) in enumerate(ranges)]
+            pv = views(p)
+            with torch.cuda.device(dev) if dev.type == "cuda" else _null():
+                eng = DenseStackEngine([w for w, _ in pv], [b for _, b in pv], [act] * (L - 1), batch=int(batch), lr=lr,
+                                       grads=views(g))
+                ds = DeviceDataset(images, labels, dev, batch, seed=data_seed + t)   # a different shuffle per tower
+            eng.bind_data(ds.x_epoch, ds.y_epoch)
+            self.params.append(p)
+            self.grads.append(g)
+            self.engines.append(eng)
+            self.datasets.append(ds)
+        self.lr = float(lr)
+        self.steps = 0
+        distinct_gpus = all(d.type == "cuda" for d in self.devices) and len({d.index for d in self.devices}) == self.n
+        self.use_rccl = distinct_gpus and self.n > 1
+        self.batches_per_epoch = self.engines[0].batches_per_epoch
+
+    def describe(self) -> str:
+        how = "torch.cuda.nccl.all_reduce (RCCL)" if self.use_rccl else "in-process sum"
+        return (f"in-graph: 1 client, {self.n} towers of a dense stack " + "-".join(str(d) for d in self.engines[0].dims)
+                + f", {self.engines[0].launches_per_step} launches per tower and step, gradient mean by {how}")
+
+    _reduce = InGraphTowers._reduce
+
+    def step(self):
+        pos = self.steps % self.batches_per_epoch
+        if pos == 0 and self.steps > 0:
+            for ds, eng in zip(self.datasets, self.engines):
+                ds.shuffle_epoch()
+                eng.bind_data(ds.x_epoch, ds.y_epoch)
+        for t, eng in enumerate(self.engines):
+            with torch.cuda.device(self.devices[t]) if self.devices[t].type == "cuda" else _null():
+                eng.step_grad(pos, scale=1.0 / self.n)
+        self._reduce()
+        for t, dev in enumerate(self.devices):
+            gs = self.params[t][0:1]
+            if dev.type == "cuda":
+                with torch.cuda.device(dev):
+                    hb.sgd_apply_(self.params[t], self.grads[t], self.engines[t].lr, 1.0, False, gs)
+            else:
+                self.params[t].sub_(self.grads[t], alpha=self.lr)
+                gs.add_(1.0)
+        for eng in self.engines:
+            eng.advance(1)
+        self.steps += 1
+
+    def run_steps(self, n: int):
+        for _ in range(n):
+            self.step()
+
+    @property
+    def device(self):
+        return self.devices[0]
+
+    @property
+    def engine(self):
+        return self.engines[0]
+
+    def last_loss(self) -> float:
+        return sum(e.last_loss() for e in self.engines) / self.n
+
+    def evaluate(self, x, y):
+        return self.engines[0].evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        return int(round(float(self.params[0][0].item())))
+
+    def replicas_identical(self) -> bool:
+        ref0 = self.params[0].cpu()
+        return all(torch.equal(ref0, p.cpu()) for p in self.params[1:])
+
+
 class InGraphEngine:
     """One client, N towers, O(1) host calls per tower per chunk (see the module docstring).
 

@@ -295,6 +295,45 @@ def test_between_graph_script_with_resident_workers_of_a_deeper_stack(tmp_path):
     assert 2 * 22 * 2 - 3 <= max(finals) <= 2 * 22 * 2         # both workers' pushes are updates of the shared step
 
 
+def test_in_graph_towers_of_a_deeper_stack_apply_the_mean_gradient(tmp_path):
+    """Two CPU towers: one step equals the fp64 autograd step on both towers' batches taken together; replicas stay
+    identical across a reshuffle; and the script form, ``tfdist.py --hidden 48,24 --num_towers 2``."""
+    import os
+    import subprocess
+    import sys
+
+    from cluster_utils import ROOT
+    from distributed_tensorflow_amd.parallel.towers import DenseInGraphTowers
+
+    rng = np.random.RandomState(0)
+    labels = rng.randint(0, 10, 400)
+    images = (rng.rand(10, 784).astype(np.float32)[labels] + 0.3 * rng.rand(400, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    tw = DenseInGraphTowers(["cpu", "cpu"], images, onehot, batch=100, lr=0.05, hidden=(32, 16), act="tanh", seed=1)
+    assert "784-32-16-10" in tw.describe() and tw.batches_per_epoch == 4
+    Ws = [w.clone() for w in tw.engines[0].W]
+    bs = [b.clone() for b in tw.engines[0].b]
+    x = torch.cat([ds.x_epoch[:100] for ds in tw.datasets])
+    y = torch.cat([ds.y_epoch[:100] for ds in tw.datasets])
+    tw.step()
+    assert tw.replicas_identical() and tw.global_step_value() == 1
+    _oracle_step(Ws, bs, ("tanh", "tanh"), x, y, 0.05)
+    for got, want in zip(tw.engines[1].W + tw.engines[1].b, Ws + bs):
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    tw.run_steps(5)                       # crosses the 4-batch epoch boundary (reshuffle)
+    assert tw.replicas_identical() and tw.global_step_value() == 6
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tfdist.py"), "--hidden", "48,24", "--activation", "relu",
+                          "--num_towers", "2", "--lr", "0.05", "--epochs", "2", "--train_size", "2200", "--logs_path",
+                          str(tmp_path)], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=300, env=dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "2 towers of a dense stack 784-48-24-10" in out.stdout and out.stdout.rstrip().endswith("Done")
+    assert "Step: 44,  Epoch:  2,  Batch:  22 of  22" in out.stdout
+    accs = [float(line.split(":")[1]) for line in out.stdout.splitlines() if line.startswith("Test-Accuracy")]
+    assert len(accs) == 2 and accs[-1] > 0.5
+
+
 def test_tfsingle_script_with_hidden_layers(tmp_path):
     import os
     import subprocess

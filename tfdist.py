@@ -28,7 +28,7 @@ FLAGS = tf.app.flags.FLAGS
 def main(_):
     import torch
 
-    from distributed_tensorflow_amd.parallel.towers import InGraphEngine, InGraphTowers
+    from distributed_tensorflow_amd.parallel.towers import DenseInGraphTowers, InGraphEngine, InGraphTowers
 
     mnist = mnist_mlp.load_data(FLAGS)
     print("worker setting up ...", flush=True)
@@ -42,7 +42,12 @@ def main(_):
         # at most two per GPU (the streams of one process share four hardware queues)
         crowded = n_gpu and max(devices.count(d) for d in devices) > 2
         exchange = "inbox" if (n_gpu and not crowded and FLAGS.activation == "sigmoid") else "rccl"
-    if exchange == "inbox" and n_gpu:
+    hidden = mnist_mlp.hidden_widths(FLAGS)
+    if hidden != (100,):
+        # any other stack: the host-loop towers around the dense-layer engine (all-reduce of the towers' gradient slabs)
+        towers = DenseInGraphTowers(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
+                                    hidden=hidden, act=FLAGS.activation, seed=1)
+    elif exchange == "inbox" and n_gpu:
         towers = InGraphEngine(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr, seed=1,
                                chunk=min(50, int(FLAGS.freq)))
     else:
