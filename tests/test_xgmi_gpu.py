@@ -206,41 +206,15 @@ def test_in_graph_engine_towers_on_one_gpu_match_the_mean_gradient_oracle(towers
     (plain pointers between the towers): bit-identical replicas that follow the CPU oracle of synchronous SGD
     on the mean of the towers' gradients, with one host call per tower per chunk.  (Two towers: the streams of one
     process share 4 hardware queues, and a third tower's spinning backward can end up queued behind a peer's.)"""
-    import numpy as np
-    import torch
+    from cluster_utils import ROOT
 
-    from distributed_tensorflow_amd.ops import reference as ref
-    from distributed_tensorflow_amd.parallel.towers import InGraphEngine
-
-    rng = np.random.RandomState(0)
-    images = rng.rand(600, 784).astype(np.float32)
-    labels = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 600)]
-    eng = InGraphEngine(["cuda:0"] * towers, images, labels, batch=100, lr=0.05, seed=1, chunk=4, compact=compact,
-                        timeout_ms=20000)
-    try:
-        p = {k: v.detach().cpu().clone() for k, v in eng.towers[0].layout.mlp_views(eng.towers[0].params).items()}
-        sets = [(tr.ds.x_epoch.cpu().clone(), tr.ds.y_epoch.cpu().clone()) for tr in eng.towers]
-        eng.prepare((5,))
-        eng.run_steps(5)                       # chunks of 4 + 1, inside the first 6-batch epoch
-        assert eng.healthy(), "an exchange between the towers timed out"
-        assert eng.global_step_value() == 5
-        assert eng.replicas_identical()
-        assert eng.host_calls_per_chunk() == 1
-        for step in range(5):
-            g = {k: torch.zeros_like(v) for k, v in p.items()}
-            for xs, ys in sets:
-                out = ref.mlp_grads(xs[100 * step:100 * step + 100], ys[100 * step:100 * step + 100], p["W1"], p["b1"],
-                                    p["W2"], p["b2"])
-                for k in g:
-                    g[k] += out["d" + k] / towers
-            for k in p:
-                p[k] -= 0.05 * g[k]
-        got = eng.towers[-1].layout.mlp_views(eng.towers[-1].params)
-        for k in p:
-            torch.testing.assert_close(got[k].cpu(), p[k], rtol=2e-4, atol=2e-5)
-        eng.run_steps(9)                       # crosses the epoch boundary: every tower reshuffles its own set
-        assert eng.healthy() and eng.replicas_identical() and eng.global_step_value() == 14
-        loss, acc = eng.evaluate(torch.as_tensor(images).cuda(), torch.as_tensor(labels).cuda())
-        assert loss == loss and 0.0 <= acc <= 1.0
-    finally:
-        eng.close()
+    # a process of its own: one engine per client process is how the engine is used
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ingraph_worker.py"), str(towers), str(int(compact))],
+                         cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+    assert res["healthy_5"], "an exchange between the towers timed out"
+    assert res["step_5"] == 5 and res["identical_5"] and res["host_calls_per_chunk"] == 1
+    assert res["oracle_error"] <= 1.0, res          # |got - oracle| <= 2e-5 + 2e-4 |oracle| everywhere
+    assert res["healthy_14"] and res["identical_14"] and res["step_14"] == 14
+    assert res["loss"] == res["loss"] and 0.0 <= res["acc"] <= 1.0
