@@ -80,13 +80,14 @@ class DenseResidentTrainer:
     def run_steps(self, n: int):
         """n steps; reshuffles the resident set at every epoch boundary."""
         bpe = self.engine.batches_per_epoch
-        for k in self._schedule(self.engine._host_cursor, n):
-            cur = self.engine._host_cursor
-            if cur % bpe == 0 and cur > 0:
-                self.ds.shuffle_epoch()
-            self._bind_active_set()
-            self.engine.run_chunk(k, use_graph=self.use_graph)
-        self.sess._gs_mirror = None         # the step counter moved behind the session's back
+        with self.sess.run_lock:            # (the Supervisor's checkpoint thread reads the same variables)
+            for k in self._schedule(self.engine._host_cursor, n):
+                cur = self.engine._host_cursor
+                if cur % bpe == 0 and cur > 0:
+                    self.ds.shuffle_epoch()
+                self._bind_active_set()
+                self.engine.run_chunk(k, use_graph=self.use_graph)
+            self.sess._gs_mirror = None     # the step counter moved behind the session's back
 
     def last_loss(self) -> float:
         return self.engine.last_loss()
@@ -374,26 +375,28 @@ class PsDenseResidentTrainer:
 
     def run_steps(self, n: int):
         bpe = self.engine.batches_per_epoch
-        for k in self._schedule(self.engine._host_cursor, n):
-            cur = self.engine._host_cursor
-            if cur % bpe == 0 and cur > 0:
-                self.ds.shuffle_epoch()
-            self._bind_active_set()
-            pos = cur % bpe
-            if self.use_graph:
-                self._graph(pos, k).replay()
-            else:
-                for i in range(k):
-                    self._one_step(pos + i)
-            self.engine.advance(k)
-        self.sess._gs_mirror = None         # the step counter moved behind the session's back
+        with self.sess.run_lock:            # (the Supervisor's checkpoint thread pulls into the same slab)
+            for k in self._schedule(self.engine._host_cursor, n):
+                cur = self.engine._host_cursor
+                if cur % bpe == 0 and cur > 0:
+                    self.ds.shuffle_epoch()
+                self._bind_active_set()
+                pos = cur % bpe
+                if self.use_graph:
+                    self._graph(pos, k).replay()
+                else:
+                    for i in range(k):
+                        self._one_step(pos + i)
+                self.engine.advance(k)
+            self.sess._gs_mirror = None     # the step counter moved behind the session's back
 
     def last_loss(self) -> float:
         return self.engine.last_loss()
 
     def evaluate(self, x: torch.Tensor, y: torch.Tensor) -> Tuple[float, float]:
-        self.store.pull(self.params)
-        return self.engine.evaluate(x, y)
+        with self.sess.run_lock:
+            self.store.pull(self.params)
+            return self.engine.evaluate(x, y)
 
     def global_step_value(self) -> int:
         return self.store.global_step()
@@ -500,19 +503,20 @@ class PsDenseSyncResidentTrainer:
 
     def run_steps(self, n: int):
         bpe = self.engine.batches_per_epoch
-        for k in self._schedule(self.engine._host_cursor, n):
-            cur = self.engine._host_cursor
-            if cur % bpe == 0 and cur > 0:
-                self.ds.shuffle_epoch()
-            self._bind_active_set()
-            pos = cur % bpe
-            if self.use_graph:
-                self._graph(pos, k, cur & 1).replay()
-            else:
-                for i in range(k):
-                    self._one_step(pos + i, (cur + i) & 1)
-            self.engine.advance(k)
-        self.sess._gs_mirror = None
+        with self.sess.run_lock:
+            for k in self._schedule(self.engine._host_cursor, n):
+                cur = self.engine._host_cursor
+                if cur % bpe == 0 and cur > 0:
+                    self.ds.shuffle_epoch()
+                self._bind_active_set()
+                pos = cur % bpe
+                if self.use_graph:
+                    self._graph(pos, k, cur & 1).replay()
+                else:
+                    for i in range(k):
+                        self._one_step(pos + i, (cur + i) & 1)
+                self.engine.advance(k)
+            self.sess._gs_mirror = None
 
     def last_loss(self) -> float:
         return self.engine.last_loss()
