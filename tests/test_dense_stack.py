@@ -334,6 +334,58 @@ def test_in_graph_towers_of_a_deeper_stack_apply_the_mean_gradient(tmp_path):
     assert len(accs) == 2 and accs[-1] > 0.5
 
 
+def test_deeper_stack_checkpoint_and_resume_through_the_supervisor(tmp_path):
+    """A deeper stack trained by the device-resident PS worker loop, checkpointed by the chief's Supervisor at the end
+    and resumed by a restarted cluster: every variable of the stack is in the bundle under its TF name."""
+    import os
+
+    from distributed_tensorflow_amd.data import DeviceDataset
+    from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+    from distributed_tensorflow_amd.parallel.dense_trainer import PsDenseResidentTrainer
+    from distributed_tensorflow_amd.train.saver import latest_checkpoint, read_bundle
+
+    logdir = str(tmp_path / "train")
+    rng = np.random.RandomState(0)
+    labels = rng.randint(0, 10, 300)
+    images = (rng.rand(10, 784).astype(np.float32)[labels] + 0.3 * rng.rand(300, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+
+    def run(steps, expect_start):
+        cluster = tf.train.ClusterSpec(cluster_dict(1, 1))
+        cfg = tf.ConfigProto(allow_soft_placement=True, operation_timeout_in_ms=20000)
+        ps = tf.train.Server(cluster, "ps", 0, config=cfg)
+        w = tf.train.Server(cluster, "worker", 0, config=cfg)
+        try:
+            with tf.Graph().as_default() as g:
+                with tf.device(tf.train.replica_device_setter(worker_device="/job:worker/task:0", cluster=cluster)):
+                    m = build_model(0.05, "relu", hidden=(32, 16))
+                sv = tf.train.Supervisor(graph=g, is_chief=True, global_step=m.global_step, init_op=m.init_op,
+                                         logdir=logdir, save_model_secs=3600)
+                with sv.prepare_or_wait_for_session(w.target) as sess:
+                    assert sess.store.global_step() == expect_start
+                    ds = DeviceDataset(images, onehot, sess.device, 50, seed=3)
+                    tr = PsDenseResidentTrainer(sess, m.train_op, ds, 50, chunk=4)
+                    tr.run_steps(steps)
+                    sess._pull()
+                    values = {v.op_name: sess.var_tensor(v).clone() for v in m.weights + m.biases}
+                    tr.close()
+                sv.stop()                     # final checkpoint by the chief
+                return values
+        finally:
+            ps.stop()
+            w.stop()
+
+    a = run(7, 0)
+    assert latest_checkpoint(logdir).endswith("model.ckpt-7") and os.path.exists(os.path.join(logdir, "model.ckpt-7.index"))
+    bundle = read_bundle(os.path.join(logdir, "model.ckpt-7"))
+    assert len(a) == 6 and set(a) <= set(bundle) and "global_step" in bundle
+    for name, value in a.items():
+        np.testing.assert_array_equal(bundle[name].reshape(-1), value.numpy().reshape(-1))
+    b = run(3, 7)                             # a restarted cluster resumes at step 7 with the saved variables
+    assert latest_checkpoint(logdir).endswith("model.ckpt-10")
+    assert any(not torch.equal(a[k], b[k]) for k in a)
+
+
 def test_tfsingle_script_with_hidden_layers(tmp_path):
     import os
     import subprocess
