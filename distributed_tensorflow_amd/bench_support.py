@@ -582,11 +582,9 @@ def run_benchmark(args) -> Optional[dict]:
             wd.hold(_result(n, steps, warmup, elapsed, parallelism, mnist.source, use_cpu, device, ranks_seen, result_extra))
         wd.stage("dense stack, data parallel", limit_s=float(os.environ.get("DTF_BENCH_DENSE_DP_S", "120")))
         try:
-            rep = _measure_dense_dp(device, rank, world)
+            rep = _measure_dense_dp(device, rank, world, agree)
         except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
             rep = {"error": f"{type(e).__name__}: {e}"}
-        if not agree("error" not in rep):
-            rep = {"error": rep.get("error", "failed on another rank")}
         result_extra["dense_dp"] = rep
 
     result = None
@@ -681,10 +679,12 @@ def _measure_dense_stacks(device) -> dict:
     return out
 
 
-def _measure_dense_dp(device, rank: int, world: int) -> dict:
+def _measure_dense_dp(device, rank: int, world: int, agree) -> dict:
     """Synchronous data-parallel steps of a 784-4096-4096-10 stack (parallel/dense_trainer.py): 80 MB of gradients per
     step in buckets, each all-reduced on a side stream under the backward of the layers below.  Every rank calls this at
-    the same place; the same steps without collectives say what the overlap has to hide."""
+    the same place; the same steps without collectives say what the overlap has to hide.  Whatever can fail on one rank
+    alone (allocation, data, construction) happens before the first collective and is followed by ``agree``: the ranks
+    either all measure or all return the error."""
     import numpy as np
     import torch.distributed as dist
 
@@ -694,15 +694,25 @@ def _measure_dense_dp(device, rank: int, world: int) -> dict:
     dims, batch, steps, warm = (784, 4096, 4096, 10), int(os.environ.get("DTF_BENCH_DENSE_DP_BATCH", "4096")), 16, 3
     if device.type == "cpu":        # CPU rehearsal of the flow (gloo): a stack small enough for a test
         dims, batch, steps, warm = (784, 64, 64, 10), 32, 4, 1
-    rng = np.random.RandomState(100 + rank)
-    rows = 4 * batch
-    images = rng.rand(rows, dims[0]).astype(np.float32)
-    onehot = np.eye(dims[-1], dtype=np.float32)[rng.randint(0, dims[-1], rows)]
-    ds = DeviceDataset(images, onehot, device, batch, seed=rank)
+    trainers, err = {}, None
+    try:
+        if os.environ.get("DTF_BENCH_TEST_FAIL") == f"dense_dp:{rank}":       # test hook: this rank cannot set up
+            raise MemoryError("injected by DTF_BENCH_TEST_FAIL")
+        rng = np.random.RandomState(100 + rank)
+        rows = 4 * batch
+        images = rng.rand(rows, dims[0]).astype(np.float32)
+        onehot = np.eye(dims[-1], dtype=np.float32)[rng.randint(0, dims[-1], rows)]
+        ds = DeviceDataset(images, onehot, device, batch, seed=rank)
+        for tag, w in (("with_collectives", world), ("compute_only", 1)):
+            trainers[tag] = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, batch, 0.01, device, rank, w, seed=1)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(err is None):
+        return {"error": err or "set-up failed on another rank"}
     out = {"model": "-".join(map(str, dims)), "batch_per_rank": batch, "ranks": world, "steps": steps, "warmup": warm,
            "dtype": "fp32", "note": "not the reference's workload: its update rule on a model whose gradients are megabytes"}
-    for tag, w in (("with_collectives", world), ("compute_only", 1)):
-        tr = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, batch, 0.01, device, rank, w, seed=1)
+    for tag in ("with_collectives", "compute_only"):
+        tr = trainers.pop(tag)
         tr.run_steps(warm)
         _sync(device, True)
         t0 = time.perf_counter()

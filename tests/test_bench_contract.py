@@ -128,3 +128,17 @@ def test_watchdog_prints_the_held_result_when_a_stage_outlives_its_limit(held):
         assert _json_line(p.stdout) == {"metric": "m", "value": 1.5, "truncated_at_stage": "optional stage"}
     else:
         assert p.returncode == 3 and p.stdout.strip() == ""
+
+
+def test_a_rank_that_cannot_set_up_the_dense_stage_costs_only_that_stage():
+    """One rank fails before the stage's first collective: the ranks agree to skip it, everything else is reported."""
+    port = free_ports(1)[0]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu",
+           "--steps", "20", "--warmup", "4"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DTF_BENCH_TEST_FAIL="dense_dp:1", DTF_BENCH_DENSE_DP_S="60"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = _json_line(p.stdout)
+    assert r["dense_dp"] == {"error": "set-up failed on another rank"} and "truncated_at_stage" not in r
+    assert r["ranks_seen"] == 2 and r["sec_per_epoch"] > 0 and r["async_mode"]["value"] > 0
