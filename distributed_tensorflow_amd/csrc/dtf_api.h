@@ -208,6 +208,13 @@ int dtf_colsum_multi(int count, const uint64_t* z, const int64_t* ldz, const int
 // *global_step += 1 (each output may be null).
 int dtf_softmax_xent_step(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
                           float* loss_out, int32_t* correct_out, float* global_step, void* stream);
+// The same head over ceil(M / 4) workgroups with nothing to clear beforehand: per-workgroup partial sums meet in `scratch`
+// (>= 2 * ceil(M / 4) + 1 floats owned by the caller; the last word is a ticket that must be zero before the first launch
+// and is zero again after every launch), the last workgroup to arrive adds them in a fixed order, STORES *loss_out and
+// *correct_out and bumps *global_step (each output may be null).
+int dtf_softmax_xent_head(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                          float* scratch, int64_t scratch_floats, float* loss_out, int32_t* correct_out,
+                          float* global_step, void* stream);
 // Start of a training step of a dense stack: *loss_sum = 0, *correct = 0, *global_step += 1 (each may be null).
 int dtf_dense_step_begin(float* loss_sum, int32_t* correct, float* global_step, void* stream);
 // Softmax cross-entropy over logits [M][C] against (soft) labels [M][C]: loss_sum += sum of the row losses, correct +=

@@ -686,6 +686,66 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   }
 }
 
+// The head of a training step over MANY workgroups without an accumulator to clear first: every workgroup leaves the
+// loss and the hit count of its 4 rows in `scratch` ([blocks] losses, [blocks] counts as floats, one ticket word, all
+// owned by the caller and zero-ticketed between launches), and the workgroup that draws the last ticket adds them in
+// block order (the same bits on every run), STORES the step's loss sum and correct count, bumps the step counter and
+// puts the ticket back to zero.  Hand-off as in the K split of the GEMM: plain stores, one agent-scope release ahead of
+// the ticket, one agent-scope acquire in the last workgroup before anybody reads.
+__global__ __launch_bounds__(256) void softmax_xent_head_kernel(const float* __restrict__ z, const float* __restrict__ y,
+                                                                int M, int C, float* dz, float grad_scale, float* scratch,
+                                                                float* loss_out, int* correct_out, float* global_step) {
+  __shared__ float wl[4];
+  __shared__ int wc[4];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  const int blocks = gridDim.x;
+  float loss = 0.f;
+  int hit = 0;
+  if (m < M) loss = xent_row(z + (long)m * C, y + (long)m * C, C, lane, dz != nullptr ? dz + (long)m * C : nullptr, grad_scale, hit);
+  if (lane == 0) {
+    wl[wave] = loss;
+    wc[wave] = hit;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scratch[blockIdx.x] = (wl[0] + wl[1]) + (wl[2] + wl[3]);
+    scratch[blocks + blockIdx.x] = (float)(wc[0] + wc[1] + wc[2] + wc[3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * blocks);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == (unsigned)blocks - 1u ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *ticket = 0u;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  // fixed order: thread t adds blocks t, t + 256, ...; then the 256 partial sums in index order
+  __shared__ float pl[256], pc[256];
+  float sl = 0.f, sc = 0.f;
+  for (int b = threadIdx.x; b < blocks; b += 256) {
+    sl += scratch[b];
+    sc += scratch[blocks + b];
+  }
+  pl[threadIdx.x] = sl;
+  pc[threadIdx.x] = sc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tl = 0.f, tc = 0.f;
+    for (int i = 0; i < 256; ++i) {
+      tl += pl[i];
+      tc += pc[i];
+    }
+    if (loss_out != nullptr) *loss_out = tl;
+    if (correct_out != nullptr) *correct_out = (int)(tc + 0.5f);
+    if (global_step != nullptr) *global_step += 1.0f;
+  }
+}
+
 // The head of a training step in ONE workgroup (batches of up to a few thousand rows): the 16 waves walk the rows 16
 // apart, the row losses are added in a fixed order, and the step's loss sum and correct count are STORED (no accumulator
 // to clear first, the same bits on every run) together with the bump of the step counter.
@@ -824,6 +884,18 @@ extern "C" int dtf_softmax_xent_step(const float* logits, const float* labels, i
 extern "C" int dtf_dense_step_begin(float* loss_sum, int32_t* correct, float* global_step, void* stream) {
   hipLaunchKernelGGL(dense_step_begin_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), loss_sum, correct,
                      global_step);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+}
+
+extern "C" int dtf_softmax_xent_head(const float* logits, const float* labels, int M, int C, float* dz, float grad_scale,
+                                     float* scratch, int64_t scratch_floats, float* loss_out, int32_t* correct_out,
+                                     float* global_step, void* stream) {
+  if (logits == nullptr || labels == nullptr || scratch == nullptr) return DTF_ERR_NULL;
+  if (M < 1 || C < 1 || M > (1 << 24)) return DTF_ERR_SHAPE;          // (counts travel as floats: exact up to 2^24)
+  const int blocks = (M + 3) / 4;
+  if (scratch_floats < 2 * (int64_t)blocks + 1) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(softmax_xent_head_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels,
+                     M, C, dz, grad_scale, scratch, loss_out, correct_out, global_step);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

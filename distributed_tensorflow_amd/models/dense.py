@@ -17,13 +17,14 @@ every launch a kernel of ``csrc/gemm.hip``:
             tfdist_between.py:65-66) or a plain store into a gradient tensor (parameter-server modes), and the bias
             gradient as a column sum with the same two endings.
 
-3 L + 2 launches per fused step of L layers: one that clears the step's loss / accuracy accumulators and bumps the step
-counter (batches of up to 16 rows fold it into a one-workgroup head), L forward GEMMs, the head, L - 1 input-gradient and
-L weight-gradient GEMMs, and ONE column-sum launch for the bias gradients of all layers (batches beyond 4096 rows: one per
+3 L + 1 launches per fused step of L layers: L forward GEMMs, the head (its last workgroup to arrive adds the
+per-workgroup sums in a fixed order, stores the step's loss and accuracy counts and bumps the step counter: nothing is
+cleared beforehand; batches of up to 16 rows use a one-workgroup head), L - 1 input-gradient and L weight-gradient GEMMs,
+and ONE column-sum launch for the bias gradients of all layers (batches beyond 4096 rows: one per
 layer, with row segments), captured into hipGraph chunks by ``run_chunk`` when the mini-batches come from a resident set.
 All launches go to the current stream in that order.  (``DTF_DENSE_OVERLAP=1`` captures a step as a graph with BRANCHES
 instead — weight gradients next to the input-gradient GEMMs of the layers below them, bias sums next to the last weight
-gradients, the reset next to the forward pass — which shortens the critical path on paper and measured slower: edges
+gradients — which shortens the critical path on paper and measured slower: edges
 between the streams of a hipGraph cost more than the launches they take off the chain.)  On CPU tensors every method runs the same mathematics
 in PyTorch, which is the soft-placement path and the test oracle.
 """
@@ -122,14 +123,15 @@ class DenseStackEngine:
         # hipGraph costs more than the 1.6 us between two launches of one stream: 76 against 59 us per step of
         # 784-100-10, 122 against 114 us of 784-1024-1024-10 at batch 100), so it is an option, not the default
         self.overlap = os.environ.get("DTF_DENSE_OVERLAP", "0") == "1"
+        self._head_scratch = hb.xent_head_scratch(self.B, dev) if self.on_gpu else None
         self._side = self._ws_side = None
 
     @property
     def launches_per_step(self) -> int:
-        """Accumulator reset + step counter, L forward GEMMs, the head, L - 1 input gradients, L weight and L bias
-        gradients (biases that exist)."""
+        """L forward GEMMs, the head (which also stores the step's statistics and bumps the step counter), L - 1 input
+        gradients, L weight gradients, one launch for the bias gradients (batches beyond 4096 rows: one per bias)."""
         biases = sum(1 for b in self.b if b is not None)
-        return 3 * self.L + (0 if self.B <= hb.XENT_STEP_MAX_ROWS else 1) + (min(1, biases) if self.B <= 4096 else biases)
+        return 3 * self.L + (min(1, biases) if self.B <= 4096 else biases)
 
     # -- data -----------------------------------------------------------------------------------------------------
     def bind_data(self, x: torch.Tensor, y: torch.Tensor, batches_per_epoch: Optional[int] = None):
@@ -191,7 +193,7 @@ class DenseStackEngine:
         """With ``self.overlap`` a CAPTURED step is a graph with branches, not a chain: the weight gradient of layer i
         needs only dz_i and the activations below, so it runs NEXT TO the input-gradient GEMMs of the layers below it
         (after the one of its own layer, which still reads the old W_i), the bias column sums run next to the last
-        weight gradients, and the accumulator reset next to the forward pass.  Eager launches stay on one stream."""
+        weight gradients.  Eager launches stay on one stream."""
         x, y = self._batch(bi)
         slot = self._slot(bi)
         loss_slot, correct_slot = self.loss_sum[slot:slot + 1], self.correct[slot:slot + 1]
@@ -201,27 +203,21 @@ class DenseStackEngine:
         branch = self.overlap and torch.cuda.is_current_stream_capturing()
         side, ws_side = self._branch_streams() if branch else (None, None)
 
+        used = set()
+
         def fork(s):        # stream s goes on from this point of the main stream
             ev = torch.cuda.Event()
             ev.record(main)
             s.wait_event(ev)
 
+        logits = self._forward_gpu(x, self.a)
         if self.B <= hb.XENT_STEP_MAX_ROWS:
             # one workgroup: loss and count stored in a fixed order, the step counter bumped in the same launch
-            logits = self._forward_gpu(x, self.a)
             hb.softmax_xent_step(logits, y, self.dz[-1], gscale, loss_slot, correct_slot, gs)
         else:
-            # (the counter's bump commutes with everything else in the step: nothing in it reads global_step)
-            if branch:
-                fork(side[2])
-                with torch.cuda.stream(side[2]):
-                    hb.dense_step_begin(loss_slot, correct_slot, gs)
-            else:
-                hb.dense_step_begin(loss_slot, correct_slot, gs)
-            logits = self._forward_gpu(x, self.a)
-            if branch:
-                main.wait_stream(side[2])
-            hb.softmax_xent(logits, y, dz=self.dz[-1], grad_scale=gscale, loss_sum=loss_slot, correct=correct_slot)
+            # four rows per workgroup; the last workgroup to arrive adds the partial sums in a fixed order, stores them
+            # and bumps the step counter: nothing to clear beforehand, no launch of its own for the counter
+            hb.softmax_xent_head(logits, y, self.dz[-1], gscale, self._head_scratch, loss_slot, correct_slot, gs)
         for i in range(self.L - 1, -1, -1):
             below = self.a[i - 1] if i > 0 else x
             if i > 0:       # before W_i changes: dz_{i-1} = (dz_i W_i^T) * act'(a_{i-1})
@@ -229,6 +225,7 @@ class DenseStackEngine:
                         act=self.acts[i - 1], aux=below, workspace=self._ws)
             if branch:
                 fork(side[i & 1])
+                used.add(i & 1)
             with torch.cuda.stream(side[i & 1]) if branch else contextlib.nullcontext():
                 ws = ws_side[i & 1] if branch else self._ws
                 if fused:
@@ -240,8 +237,8 @@ class DenseStackEngine:
             fork(side[2])
             with torch.cuda.stream(side[2]):
                 self._bias_gradients(fused)
-            for s in side:
-                main.wait_stream(s)
+            for k in sorted(used | {2}):
+                main.wait_stream(side[k])
         else:
             self._bias_gradients(fused)
 

@@ -150,7 +150,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_colsum_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, f32, vp, vp]
     lib.dtf_colsum_multi.restype = C.c_int
     lib.dtf_softmax_xent_step.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp, vp, vp]
-    for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent", "dtf_dense_step_begin", "dtf_softmax_xent_step"):
+    lib.dtf_softmax_xent_head.argtypes = [vp, vp, i32, i32, vp, f32, vp, C.c_int64, vp, vp, vp, vp]
+    for name in ("dtf_gemm_f32", "dtf_colsum", "dtf_softmax_xent", "dtf_dense_step_begin", "dtf_softmax_xent_step",
+                 "dtf_softmax_xent_head"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_debug_force_generic_path.argtypes = [i32]
     lib.dtf_debug_force_generic_path.restype = None
@@ -452,6 +454,28 @@ def softmax_xent_step(logits, labels, dz: torch.Tensor, grad_scale: float, loss_
     M, Cn = logits.shape
     _check(lib.dtf_softmax_xent_step(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(loss_out),
                                      _ptr(correct_out), _ptr(global_step), _stream()), "dtf_softmax_xent_step")
+
+
+def xent_head_scratch(rows: int, device) -> torch.Tensor:
+    """Scratch of :func:`softmax_xent_head` for batches of up to ``rows`` rows (zeroed: its last word is the ticket)."""
+    return torch.zeros(2 * ((int(rows) + 3) // 4) + 4, dtype=torch.float32, device=device)
+
+
+def softmax_xent_head(logits, labels, dz: torch.Tensor, grad_scale: float, scratch: torch.Tensor, loss_out: torch.Tensor,
+                      correct_out: torch.Tensor, global_step: Optional[torch.Tensor] = None):
+    """The head of a training step over many workgroups in ONE launch with nothing to clear first: per-workgroup sums meet
+    in ``scratch`` (``xent_head_scratch``; one per engine, steps in stream order), the last workgroup adds them in a fixed
+    order, stores the loss sum (float32[1]) and the correct count (int32[1]) and bumps ``global_step``."""
+    lib = require()
+    _f32c(logits, "logits"), _f32c(labels, "labels"), _f32c(dz, "dz"), _f32c(loss_out, "loss_out"), _f32c(scratch, "scratch")
+    if logits.dim() != 2 or labels.shape != logits.shape or dz.shape != logits.shape:
+        raise HipKernelError("softmax_xent_head: logits, labels and dz must be equally shaped 2-D tensors")
+    if correct_out.dtype != torch.int32 or correct_out.numel() != 1 or loss_out.numel() != 1:
+        raise HipKernelError("softmax_xent_head: one float32 loss and one int32 count")
+    M, Cn = logits.shape
+    _check(lib.dtf_softmax_xent_head(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(scratch),
+                                     scratch.numel(), _ptr(loss_out), _ptr(correct_out), _ptr(global_step), _stream()),
+           "dtf_softmax_xent_head")
 
 
 def dense_step_begin(loss_sum: Optional[torch.Tensor], correct: Optional[torch.Tensor],

@@ -213,13 +213,12 @@ class DenseDataParallelTrainer:
         slot = eng._slot(bi)
         main = torch.cuda.current_stream(self.device)
         loss_slot, correct_slot = eng.loss_sum[slot:slot + 1], eng.correct[slot:slot + 1]
+        logits = eng._forward_gpu(x, eng.a)
         if eng.B <= hb.XENT_STEP_MAX_ROWS:
-            logits = eng._forward_gpu(x, eng.a)
             hb.softmax_xent_step(logits, y, eng.dz[-1], 1.0 / eng.B, loss_slot, correct_slot, self.global_step)
         else:
-            hb.dense_step_begin(loss_slot, correct_slot, self.global_step)
-            logits = eng._forward_gpu(x, eng.a)
-            hb.softmax_xent(logits, y, dz=eng.dz[-1], grad_scale=1.0 / eng.B, loss_sum=loss_slot, correct=correct_slot)
+            hb.softmax_xent_head(logits, y, eng.dz[-1], 1.0 / eng.B, eng._head_scratch, loss_slot, correct_slot,
+                                 self.global_step)
         for i in range(eng.L - 1, -1, -1):
             below = eng.a[i - 1] if i > 0 else x
             gw, gb = eng.g[i]

@@ -208,6 +208,35 @@ def test_softmax_xent_step_one_workgroup_head(M, C):
     assert torch.equal(again, loss) and float(gs) == 42.0         # a fixed order of additions; no counter given, none bumped
 
 
+@pytest.mark.parametrize("M,C", [(100, 10), (17, 3), (1000, 37), (4096, 10), (10001, 5)])
+def test_softmax_xent_head_many_workgroups_stores_without_a_reset(M, C):
+    """Per-workgroup sums meet in a scratch buffer, the last workgroup to arrive adds them in a fixed order and STORES
+    the statistics: stale outputs do not matter, the ticket is back at zero afterwards, repeated launches give the same bits."""
+    z = _rand(M, C, scale=3.0, seed=61)
+    y = torch.zeros(M, C, device=DEV)
+    y[torch.arange(M), torch.randint(0, C, (M,), generator=torch.Generator().manual_seed(62))] = 1.0
+    zd = z.double().requires_grad_(True)
+    rows = -(y.double() * torch.log_softmax(zd, 1)).sum(1)
+    rows.sum().backward()
+    dz = torch.empty_like(z)
+    scratch = hb.xent_head_scratch(M, DEV)
+    loss = torch.full((1,), 123.0, device=DEV)
+    correct = torch.full((1,), 77, dtype=torch.int32, device=DEV)
+    gs = torch.tensor([41.0], device=DEV)
+    hb.softmax_xent_head(z, y, dz, 1.0 / M, scratch, loss, correct, gs)
+    torch.testing.assert_close(loss[0], rows.sum().detach().float(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dz, (zd.grad / M).float(), rtol=1e-4, atol=1e-6)
+    assert int(correct.item()) == int((z.argmax(1) == y.argmax(1)).sum().item()) and float(gs) == 42.0
+    blocks = (M + 3) // 4
+    assert int(scratch[2 * blocks:2 * blocks + 1].view(torch.int32).item()) == 0
+    for _ in range(3):
+        again, c2 = torch.empty(1, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV)
+        hb.softmax_xent_head(z, y, dz, 1.0 / M, scratch, again, c2, None)
+        assert torch.equal(again, loss) and torch.equal(c2, correct) and float(gs) == 42.0
+    with pytest.raises(hb.HipKernelError):
+        hb.softmax_xent_head(z, y, dz, 1.0 / M, scratch[:blocks], loss, correct, gs)        # scratch too small
+
+
 def test_colsum_multi_one_launch_for_several_matrices():
     zs = [_rand(100, n, scale=0.1, seed=40 + n) for n in (10, 300, 64, 1)]
     outs = [_rand(n, seed=50 + n) for n in (10, 300, 64, 1)]
