@@ -201,6 +201,44 @@ def _child_async_rccl(rank: int, dev_index: int, world: int, steps: int, warmup:
     return {"error": f"{note}: {text[-300:]}"}
 
 
+def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 150.0) -> dict:
+    """In-graph replication measured by a client process of its own (``bench.py --mode ingraph``): one engine per
+    process is how the engine is used and tested, and a rank that has built half a dozen trainers before is not that;
+    whatever happens to the client stays in the client."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--mode", "ingraph", "--steps", str(steps),
+           "--warmup", str(warmup), "--chunk", str(chunk)]
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                  "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+                                                  "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+            env.pop(k)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=limit_s)
+        text, note = r.stdout, f"client exited {r.returncode}"
+    except subprocess.TimeoutExpired as e:
+        text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = f"client killed after {limit_s:.0f} s"
+    for line in reversed(text.splitlines()):
+        if line.startswith("{"):
+            try:
+                doc = json.loads(line)
+            except ValueError:
+                break
+            rep = {k: doc[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup") if k in doc}
+            rep["parallelism"] = doc.get("config", {}).get("parallelism")
+            for k in ("towers", "replicas_identical", "healthy", "global_step", "host_calls_per_tower_per_chunk",
+                      "test_accuracy_after_run", "test_loss_after_run", "by_exchange_ms_per_step"):
+                if k in doc:
+                    rep[k] = doc[k]
+            rep["measured_in"] = "a client process of its own"
+            return rep
+    return {"error": f"{note}: {text[-300:]}"}
+
+
 def run_benchmark(args) -> Optional[dict]:
     import torch.distributed as dist
 
@@ -549,9 +587,11 @@ def run_benchmark(args) -> Optional[dict]:
         rep = None
         if rank == 0:
             try:
-                rep = _measure_ingraph(n, share_gpu or torch.cuda.device_count() < n, mnist, min(warmup, bpe),
-                                       min(steps, 4 * bpe) if not ingraph_only else steps, int(args.chunk), test_x, test_y,
-                                       use_cpu)
+                if ingraph_only:
+                    rep = _measure_ingraph(n, share_gpu or torch.cuda.device_count() < n, mnist, min(warmup, bpe), steps,
+                                           int(args.chunk), test_x, test_y, use_cpu)
+                else:
+                    rep = _child_ingraph(n, min(steps, 4 * bpe), min(warmup, bpe), int(args.chunk))
             except Exception as e:  # noqa: BLE001
                 rep = {"error": f"{type(e).__name__}: {e}"}
             result_extra["ingraph_mode"] = rep
