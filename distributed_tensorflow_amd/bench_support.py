@@ -201,6 +201,40 @@ def _child_async_rccl(rank: int, dev_index: int, world: int, steps: int, warmup:
     return {"error": f"{note}: {text[-300:]}"}
 
 
+def _child_dense_dp(rank: int, dev_index: int, world: int, backend: str, limit_s: float) -> dict:
+    """The data-parallel dense-stack stage in a child process per rank with a rendezvous of its own
+    (parallel/dense_dp_probe.py): a crash or a hang in there costs the caller nothing but this stage."""
+    import subprocess
+
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 83
+    if port > 65000:
+        port -= 1000
+    cmd = [sys.executable, "-m", "distributed_tensorflow_amd.parallel.dense_dp_probe", "--rank", str(rank),
+           "--world", str(world), "--device", str(dev_index), "--port", str(port), "--backend", backend]
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                  "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+                                                  "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+            env.pop(k)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=limit_s)
+        text, note = r.stdout, f"child exited {r.returncode}"
+    except subprocess.TimeoutExpired as e:
+        text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = f"child killed after {limit_s:.0f} s"
+    for line in reversed(text.splitlines()):
+        if line.startswith("{"):
+            try:
+                doc = json.loads(line)
+                doc["measured_in"] = "child processes with a rendezvous of their own"
+                return doc
+            except ValueError:
+                break
+    return {"error": f"{note}: {text[-300:]}"}
+
+
 def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 150.0) -> dict:
     """In-graph replication measured by a client process of its own (``bench.py --mode ingraph``): one engine per
     process is how the engine is used and tested, and a rank that has built half a dozen trainers before is not that;
@@ -620,9 +654,17 @@ def run_benchmark(args) -> Optional[dict]:
     if want_dense_dp and within_budget():
         if rank == 0 and best is not None:      # what is printed should this stage hang in a collective
             wd.hold(_result(n, steps, warmup, elapsed, parallelism, mnist.source, use_cpu, device, ranks_seen, result_extra))
-        wd.stage("dense stack, data parallel", limit_s=float(os.environ.get("DTF_BENCH_DENSE_DP_S", "120")))
+        dp_limit = float(os.environ.get("DTF_BENCH_DENSE_DP_S", "120"))
+        wd.stage("dense stack, data parallel", limit_s=dp_limit + 30.0)
         try:
-            rep = _measure_dense_dp(device, rank, world, agree)
+            if use_cpu:         # (CPU rehearsal of the flow: in this process, over the gloo group at hand)
+                from .parallel.dense_dp_probe import measure as _measure_dense_dp
+
+                rep = _measure_dense_dp(device, rank, world, agree)
+            else:
+                _sync(device, distributed)
+                rep = _child_dense_dp(rank, dev_index, world, "gloo" if share_gpu else "nccl", dp_limit)
+                _sync(device, distributed)              # every rank's child is gone before anything else starts
         except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
             rep = {"error": f"{type(e).__name__}: {e}"}
         result_extra["dense_dp"] = rep
@@ -716,63 +758,6 @@ def _measure_dense_stacks(device) -> dict:
             "ms_per_step": round(1000.0 * dt, 5), "samples_per_s": round(batch / dt, 1),
             "gemm_tflops": round(flop / dt / 1e12, 1), "launches_per_step": eng.launches_per_step, "dtype": "fp32"}
         del eng, Ws, bs, x, y
-    return out
-
-
-def _measure_dense_dp(device, rank: int, world: int, agree) -> dict:
-    """Synchronous data-parallel steps of a 784-4096-4096-10 stack (parallel/dense_trainer.py): 80 MB of gradients per
-    step in buckets, each all-reduced on a side stream under the backward of the layers below.  Every rank calls this at
-    the same place; the same steps without collectives say what the overlap has to hide.  Whatever can fail on one rank
-    alone (allocation, data, construction) happens before the first collective and is followed by ``agree``: the ranks
-    either all measure or all return the error."""
-    import numpy as np
-    import torch.distributed as dist
-
-    from .data import DeviceDataset
-    from .parallel.dense_trainer import DenseDataParallelTrainer
-
-    dims, batch, steps, warm = (784, 4096, 4096, 10), int(os.environ.get("DTF_BENCH_DENSE_DP_BATCH", "4096")), 16, 3
-    if device.type == "cpu":        # CPU rehearsal of the flow (gloo): a stack small enough for a test
-        dims, batch, steps, warm = (784, 64, 64, 10), 32, 4, 1
-    trainers, err = {}, None
-    try:
-        if os.environ.get("DTF_BENCH_TEST_FAIL") == f"dense_dp:{rank}":       # test hook: this rank cannot set up
-            raise MemoryError("injected by DTF_BENCH_TEST_FAIL")
-        rng = np.random.RandomState(100 + rank)
-        rows = 4 * batch
-        images = rng.rand(rows, dims[0]).astype(np.float32)
-        onehot = np.eye(dims[-1], dtype=np.float32)[rng.randint(0, dims[-1], rows)]
-        ds = DeviceDataset(images, onehot, device, batch, seed=rank)
-        for tag, w in (("with_collectives", world), ("compute_only", 1)):
-            trainers[tag] = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, batch, 0.01, device, rank, w, seed=1)
-    except Exception as e:  # noqa: BLE001
-        err = f"{type(e).__name__}: {e}"
-    if not agree(err is None):
-        return {"error": err or "set-up failed on another rank"}
-    out = {"model": "-".join(map(str, dims)), "batch_per_rank": batch, "ranks": world, "steps": steps, "warmup": warm,
-           "dtype": "fp32", "note": "not the reference's workload: its update rule on a model whose gradients are megabytes"}
-    for tag in ("with_collectives", "compute_only"):
-        tr = trainers.pop(tag)
-        tr.run_steps(warm)
-        _sync(device, True)
-        t0 = time.perf_counter()
-        tr.run_steps(steps)
-        _sync(device, True)
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dt = float(dt.item())
-        out[tag] = {"ms_per_step": round(1000.0 * dt / steps, 4), "samples_per_s": round(world * batch * steps / dt, 1)}
-        if tag == "with_collectives":
-            out["parallelism"] = tr.describe()
-            out["global_step"] = tr.global_step_value()
-            ck = torch.tensor([tr.replica_checksum()], dtype=torch.float64, device=device)
-            lo, hi = ck.clone(), ck.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            out["replicas_identical"] = bool(float(lo.item()) == float(hi.item()))
-            out["last_loss"] = round(tr.last_loss(), 4)
-        del tr
-    out["exposed_collective_ms_per_step"] = round(out["with_collectives"]["ms_per_step"] - out["compute_only"]["ms_per_step"], 4)
     return out
 
 
