@@ -82,6 +82,24 @@ def measure(device, rank: int, world: int, agree) -> dict:
             out["last_loss"] = round(tr.last_loss(), 4)
         del tr
     out["exposed_collective_ms_per_step"] = round(out["with_collectives"]["ms_per_step"] - out["compute_only"]["ms_per_step"], 4)
+    # what the links give a collective of a bucket's size on its own (bus bandwidth of a ring: 2 (N - 1) / N of the bytes)
+    if world > 1:
+        floats = (16 << 20) if dist.get_backend() == "nccl" else (1 << 20)
+        buf = torch.ones(floats, dtype=torch.float32, device=device)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        _sync(device)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        _sync(device)
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sec = float(dt.item())
+        out["allreduce_alone"] = {"megabytes": floats * 4 >> 20, "ms": round(1000.0 * sec, 4),
+                                  "bus_GB_per_s": round(2.0 * (world - 1) / world * floats * 4 / sec / 1e9, 1),
+                                  "backend": dist.get_backend()}
     return out
 
 

@@ -56,6 +56,7 @@ def test_two_ranks_over_gloo_report_the_aggregate(mode):
         d = r["dense_dp"]                             # a stack with bucketed gradient all-reduces, same two ranks
         assert d["replicas_identical"] is True and d["ranks"] == 2 and d["global_step"] == d["steps"] + d["warmup"]
         assert d["with_collectives"]["samples_per_s"] > 0 and d["compute_only"]["ms_per_step"] > 0
+        assert d["allreduce_alone"]["bus_GB_per_s"] > 0 and d["allreduce_alone"]["backend"] == "gloo"
     else:                 # asynchronous parameter servers: every worker's gradient is its own update
         assert r["global_step"] == 2 * 24 and "send/recv" in r["config"]["parallelism"]
 
@@ -107,6 +108,7 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     d = doc["dense_dp"]                                     # wide stack, gradient buckets reduced on a side stream
     assert d["replicas_identical"] is True and d["global_step"] == d["steps"] + d["warmup"], d
     assert d["model"] == "784-4096-4096-10" and d["with_collectives"]["samples_per_s"] > 0
+    assert d["allreduce_alone"]["ms"] > 0
 
 
 @pytest.mark.parametrize("held", [True, False])
