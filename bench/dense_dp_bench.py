@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--bucket_mb", type=float, default=32.0)
+    ap.add_argument("--graph", type=int, default=0, help="1: hipGraph chunks of 8 steps (collectives on a branch of the graph)")
+    ap.add_argument("--force_collectives", type=int, default=0,
+                    help="1: a lone rank still issues its all-reduces through a one-rank RCCL communicator")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -34,6 +37,8 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    elif a.force_collectives:
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:29871", device_id=device)
     dims = [int(v) for v in a.widths.split(",")]
     rng = np.random.RandomState(rank)
     n = 8 * a.batch
@@ -43,9 +48,10 @@ def main():
     ds = DeviceDataset(images, onehot, device, a.batch, seed=rank)
     out = {}
     for tag, w in (("with_collectives", world), ("compute_only", 1)):
+        group = dist.group.WORLD if (a.force_collectives and world == 1 and tag == "with_collectives") else None
         tr = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, a.batch, 0.01, device, rank, w, seed=1,
-                                      bucket_mb=a.bucket_mb)
-        tr.run_steps(5)
+                                      bucket_mb=a.bucket_mb, group=group, use_graph=bool(a.graph))
+        tr.run_steps(16)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

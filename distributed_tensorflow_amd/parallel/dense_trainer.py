@@ -122,7 +122,7 @@ class DenseDataParallelTrainer:
     name = "dense-dp"
 
     def __init__(self, dims, acts, dataset, batch: int, lr: float, device, rank: int = 0, world: int = 1, seed: int = 1,
-                 bucket_mb: float = 32.0, group=None):
+                 bucket_mb: float = 32.0, group=None, use_graph: bool = False, chunk: int = 8):
         from ..ops import hip_backend as hb
 
         self.hb = hb
@@ -177,12 +177,30 @@ class DenseDataParallelTrainer:
             import torch.distributed as dist
 
             self._host_reduce = dist.get_backend(group) == "gloo"
+        # hipGraph chunks (small batches, where a step is launch-bound): the side stream joins the capture through the
+        # events of _step, so a chunk is ONE graph whose collectives run on their own branch.  Not with gloo (host copies).
+        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not self._host_reduce
+        self.chunk = max(1, int(chunk))
+        self._graphs = {}
+        if self.use_graph:
+            # load every kernel (and set the communicator up) outside any capture: gradients of zero weight, an update
+            # of zero size, one small collective that every rank issues here alike
+            import torch.distributed as dist
+
+            self.engine.step_grad(0, 0.0)
+            self.hb.sgd_apply_(self.params[:4], self.grads[:4], self.lr, 0.0)
+            if self._reduce:
+                with torch.cuda.stream(self._side):
+                    dist.all_reduce(torch.zeros(4, device=self.device), group=self.group)
+            self.grads.zero_()
+            torch.cuda.synchronize(self.device)
 
     def describe(self) -> str:
         mb = [round((b - a) * 4 / (1 << 20), 2) for a, b in self.buckets]
         return (f"dense stack {'-'.join(str(n) for n in self.engine.dims)} dp{self.world}: all-reduce of {len(mb)} "
                 f"gradient bucket(s) {mb} MB on a side stream under the backward of the layers below, SGD on the reduced "
-                f"range, {'RCCL' if self.device.type == 'cuda' and not self._host_reduce else 'gloo'}")
+                f"range, {'RCCL' if self.device.type == 'cuda' and not self._host_reduce else 'gloo'}"
+                + (f", hipGraph chunks of {self.chunk}" if self.use_graph else ""))
 
     # -- one step -------------------------------------------------------------------------------------------------
     def _reduce_apply(self, k: int):
@@ -237,16 +255,39 @@ class DenseDataParallelTrainer:
                     self._reduce_apply(k)
         main.wait_stream(self._side)            # the next forward reads the updated parameters
 
+    def _graph(self, pos: int, k: int):
+        key = (pos, k)
+        g = self._graphs.get(key)
+        if g is None:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for i in range(k):
+                    self._step(pos + i)
+            self._graphs[key] = g
+        return g
+
     def run_steps(self, n: int):
         eng = self.engine
         bpe = eng.batches_per_epoch
-        for _ in range(n):
+        while n > 0:
             cur = eng._host_cursor
             if cur % bpe == 0 and cur > 0:
                 self.ds.shuffle_epoch()
-                eng.bind_data(self.ds.x_epoch, self.ds.y_epoch)
-            self._step(cur % bpe)
-            eng._host_cursor += 1
+                eng.bind_data(self.ds.x_epoch, self.ds.y_epoch)     # (same storage: the captured chunks stay valid)
+            k = min(n, self.chunk, bpe - cur % bpe) if self.use_graph else 1
+            if self.use_graph:
+                try:
+                    self._graph(cur % bpe, k).replay()
+                except Exception as e:  # noqa: BLE001 — a runtime that cannot capture the collectives: eager from here on
+                    print(f"[dense-dp] graph capture failed ({type(e).__name__}: {e}); issuing steps eagerly", flush=True)
+                    self.use_graph = False
+                    self._graphs.clear()
+                    continue
+            else:
+                self._step(cur % bpe)
+            eng._host_cursor += k
+            n -= k
 
     def prepare(self, steps_hint=()):
         pass
@@ -264,7 +305,7 @@ class DenseDataParallelTrainer:
         return float(self.params.double().sum())
 
     def close(self):
-        pass
+        self._graphs.clear()
 
 
 class PsDenseResidentTrainer:

@@ -190,7 +190,10 @@ def test_data_parallel_trainer_reduces_through_rccl_on_its_side_stream():
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
     assert res["backend"] == "nccl" and "RCCL" in res["desc"] and res["buckets"] == 2
     assert res["identical"] is True and res["global_step"] == 30           # parameters: bit for bit
-    assert abs(res["loss"] - res["loss_without"]) < 1e-6 and res["loss"] < 1.0  # (the loss is summed with atomics)
+    assert abs(res["loss"] - res["loss_without"]) < 1e-6 and res["loss"] < 1.0
+    # and as hipGraph chunks of 5 steps (the collectives on their own branch of the graph): the same bits again
+    assert res["graph_used"] is True and res["graph_identical"] is True and res["graph_step"] == 30, res
+    assert "hipGraph chunks of 5" in res["graph_desc"] and [0, 5] in res["graph_keys"] and [10, 2] in res["graph_keys"]
 
 
 def test_stack_without_biases_and_with_tall_batch():
