@@ -103,6 +103,53 @@ def measure(device, rank: int, world: int, agree) -> dict:
     return out
 
 
+def measure_small_batch(device, rank: int, world: int, agree) -> dict:
+    """The same trainer where a step is launch-bound (784-1024-1024-10, batch 100 per rank): eager launches against
+    hipGraph chunks of 8 steps whose collectives sit on a branch of the graph."""
+    import numpy as np
+    import torch.distributed as dist
+
+    from ..data import DeviceDataset
+    from .dense_trainer import DenseDataParallelTrainer
+
+    dims, batch, steps, warm = (784, 1024, 1024, 10), 100, 160, 16
+    if device.type == "cpu":
+        dims, batch, steps, warm = (784, 32, 32, 10), 20, 8, 4
+    trainers, err = {}, None
+    try:
+        rng = np.random.RandomState(200 + rank)
+        rows = 16 * batch
+        images = rng.rand(rows, dims[0]).astype(np.float32)
+        onehot = np.eye(dims[-1], dtype=np.float32)[rng.randint(0, dims[-1], rows)]
+        ds = DeviceDataset(images, onehot, device, batch, seed=rank)
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(err is None):
+        return {"error": err or "set-up failed on another rank"}
+    out = {"model": "-".join(map(str, dims)), "batch_per_rank": batch, "steps": steps}
+    for tag, graph in (("eager", False), ("graph_chunks", True)):
+        # (constructed by all ranks at the same place: with graphs the constructor issues one small collective)
+        tr = DenseDataParallelTrainer(dims, ["relu"] * (len(dims) - 2), ds, batch, 0.01, device, rank, world, seed=1,
+                                      bucket_mb=1.0, use_graph=graph, chunk=8)
+        tr.run_steps(warm)
+        _sync(device)
+        t0 = time.perf_counter()
+        tr.run_steps(steps)
+        _sync(device)
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        sec = float(dt.item())
+        ck = torch.tensor([tr.replica_checksum()], dtype=torch.float64, device=device)
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out[tag] = {"ms_per_step": round(1000.0 * sec / steps, 4), "samples_per_s": round(world * batch * steps / sec, 1),
+                    "replicas_identical": bool(float(lo.item()) == float(hi.item())), "graphs_used": bool(tr.use_graph)}
+        tr.close()
+        del tr
+    return out
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--rank", type=int, required=True)
@@ -129,6 +176,11 @@ def main(argv=None) -> int:
             return bool(int(flag.item()))
 
         out = measure(dev, args.rank, args.world, agree)
+        print(json.dumps(out), flush=True)          # (the caller reads the LAST line: what follows may not get that far)
+        try:
+            out["small_batch"] = measure_small_batch(dev, args.rank, args.world, agree)
+        except Exception as e:  # noqa: BLE001
+            out["small_batch"] = {"error": f"{type(e).__name__}: {e}"}
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer

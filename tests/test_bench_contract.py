@@ -109,6 +109,8 @@ def test_two_ranks_sharing_the_gpu_rehearse_the_peer_exchange_flow():
     assert d["replicas_identical"] is True and d["global_step"] == d["steps"] + d["warmup"], d
     assert d["model"] == "784-4096-4096-10" and d["with_collectives"]["samples_per_s"] > 0
     assert d["allreduce_alone"]["ms"] > 0
+    sb = d["small_batch"]                                   # launch-bound steps: eager against hipGraph chunks (RCCL only)
+    assert sb["eager"]["replicas_identical"] and sb["graph_chunks"]["replicas_identical"] and sb["eager"]["ms_per_step"] > 0
 
 
 @pytest.mark.parametrize("held", [True, False])
