@@ -115,6 +115,8 @@ def measure_small_batch(device, rank: int, world: int, agree) -> dict:
     dims, batch, steps, warm = (784, 1024, 1024, 10), 100, 160, 16
     if device.type == "cpu":
         dims, batch, steps, warm = (784, 32, 32, 10), 20, 8, 4
+    elif dist.get_backend() == "gloo":      # (rehearsal with ranks sharing a GPU: reductions through the host, no graphs)
+        steps, warm = 16, 4
     trainers, err = {}, None
     try:
         rng = np.random.RandomState(200 + rank)
