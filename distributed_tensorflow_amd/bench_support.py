@@ -250,6 +250,9 @@ def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float =
                                                   "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
                                                   "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
             env.pop(k)
+    # the client itself, not a launcher with the client as ITS child (which a kill at the time limit would orphan); and
+    # its own watchdog ends it should the kill not reach it
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DTF_BENCH_DEADLINE_S=str(int(limit_s)))
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=limit_s)
         text, note = r.stdout, f"client exited {r.returncode}"
