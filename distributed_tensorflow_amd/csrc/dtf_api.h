@@ -112,9 +112,10 @@ int dtf_accumulate(float* acc, const float* g, int64_t n, void* stream);
 // function of (seed, offset + i).
 int dtf_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, float mean,
                       float stddev, void* stream);
-// dst[i, :] = src[idx[i], :]   (epoch shuffle of the resident dataset)
+// dst[i, :] = src[idx[i], :]   (epoch shuffle of the resident dataset).  Indices outside [0, src_rows) are clamped
+// and, with err != null (two ints on the device), counted in err[0]; err[1] = the first such position of idx.
 int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int cols,
-                    void* stream);
+                    int64_t src_rows, int* err, void* stream);
 
 // Epoch refresh in one launch (gram.hip): dst[r] = src[perm[r]] for r < nb * B (dst may be null) and
 // gram[j][m][i] = 1 + x_{j+1}[m] . x_j[i] over the epoch-ordered rows (zero for B <= i < ld), fp32 MFMA.

@@ -574,6 +574,25 @@ struct XgParams {
 // next ones aimed at the same slot, can arrive.  A link carries 4 bytes per gradient element and step.
 constexpr uint32_t kXgEmpty = 0xffffffffu;
 
+// What a thread leaves behind when it gives up waiting (first one per replica wins the record, all are counted):
+// state[3] ticket, [4] workgroup, [5] thread, [6] peer whose word is missing, [7] expected exchange number,
+// [8] / [9] upper / lower half of the word last seen there, [10] element, [11] own rank, [12] threads that gave up.
+// The host prints the record with the error (PeerInbox.diagnose) instead of leaving a bare "exchange failed".
+__device__ __forceinline__ void xg_report_timeout(const XgParams& x, unsigned seq, long e, int peer, uint64_t seen) {
+  uint32_t* s = x.state;
+  atomicAdd(&s[12], 1u);
+  if (atomicCAS(&s[3], 0u, 1u) == 0u) {
+    s[4] = blockIdx.y * gridDim.x + blockIdx.x;
+    s[5] = threadIdx.x;
+    s[6] = (uint32_t)peer;
+    s[7] = seq;
+    s[8] = (uint32_t)(seen >> 32);
+    s[9] = (uint32_t)seen;
+    s[10] = (uint32_t)e;
+    s[11] = (uint32_t)x.rank;
+  }
+}
+
 template <int W>
 __device__ __forceinline__ float xg_exchange_compact(const XgParams& x, unsigned seq, long e, float own, int* failed) {
   uint32_t bits = __float_as_uint(own);
@@ -602,6 +621,11 @@ __device__ __forceinline__ float xg_exchange_compact(const XgParams& x, unsigned
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
       if (now - t0 > x.timeout_ticks) {
+        int peer = -1;
+#pragma unroll
+        for (int r = W - 1; r >= 0; --r)
+          if (r < x.world && r != x.rank && v[r] == kXgEmpty) peer = r;
+        xg_report_timeout(x, seq, e, peer, (uint64_t)kXgEmpty);
         *failed = 1;
         return own;
       }
@@ -649,6 +673,15 @@ __device__ __forceinline__ float xg_exchange(const XgParams& x, unsigned seq, lo
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
       if (now - t0 > x.timeout_ticks) {
+        int peer = -1;
+        uint64_t seen = 0;
+#pragma unroll
+        for (int r = W - 1; r >= 0; --r)
+          if (r < x.world && r != x.rank && (unsigned)(v[r] >> 32) != seq) {
+            peer = r;
+            seen = v[r];
+          }
+        xg_report_timeout(x, seq, e, peer, seen);
         *failed = 1;
         return own;
       }
@@ -729,6 +762,15 @@ __device__ __forceinline__ float xg_exchange_two_phase(const XgParams& x, unsign
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
       if (now - t0 > x.timeout_ticks) {
+        int peer = -1;
+        uint64_t seen = 0;
+#pragma unroll
+        for (int r = W - 1; r >= 0; --r)
+          if (r < x.world && r != x.rank && (is_owner || r == owner) && (unsigned)(v[r] >> 32) != seq) {
+            peer = r;
+            seen = v[r];
+          }
+        xg_report_timeout(x, seq, e, peer, seen);
         *failed = 1;
         return old;
       }

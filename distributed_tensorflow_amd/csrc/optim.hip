@@ -168,17 +168,24 @@ __global__ __launch_bounds__(kBlock) void philox_normal_kernel(float* __restrict
   }
 }
 
+// err (may be null): [0] number of indices found outside [0, src_rows), [1] the first such row of idx.  A bad index is
+// clamped, so a corrupted permutation is REPORTED (hb.gather_errors) instead of faulting the device.
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ src,
                                                              const int64_t* __restrict__ idx,
                                                              float* __restrict__ dst, int64_t rows,
-                                                             int cols) {
+                                                             int cols, int64_t src_rows, int* __restrict__ err) {
   // one wave per row, 16-B vectors when the row length allows
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
   const bool vec = (cols & 3) == 0;
   for (int64_t r = wave; r < rows; r += nwaves) {
-    const float* s = src + idx[r] * (int64_t)cols;
+    int64_t from = idx[r];
+    if (from < 0 || from >= src_rows) {
+      if (err && lane == 0 && atomicAdd(&err[0], 1) == 0) err[1] = (int)r;
+      from = from < 0 ? 0 : src_rows - 1;
+    }
+    const float* s = src + from * (int64_t)cols;
     float* d = dst + r * (int64_t)cols;
     if (vec) {
       const f32x4* s4 = reinterpret_cast<const f32x4*>(s);
@@ -252,15 +259,15 @@ extern "C" int dtf_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t 
 }
 
 extern "C" int dtf_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int cols,
-                               void* stream) {
+                               int64_t src_rows, int* err, void* stream) {
   if (!src || !idx || !dst) return DTF_ERR_NULL;
-  if (rows < 0 || cols <= 0) return DTF_ERR_SHAPE;
+  if (rows < 0 || cols <= 0 || src_rows < 1) return DTF_ERR_SHAPE;
   if (rows == 0) return DTF_OK;
   if ((cols & 3) == 0 && (!aligned16(src) || !aligned16(dst))) return DTF_ERR_SHAPE;
   int64_t blocks = (rows * 64 + kBlock - 1) / kBlock;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((int)blocks), dim3(kBlock), 0, (hipStream_t)stream, src,
-                     idx, dst, rows, cols);
+                     idx, dst, rows, cols, src_rows, err);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 

@@ -317,8 +317,19 @@ class DeviceDataset:
         return self._sets[self.active]["gram"]
 
     # -- producing one epoch order ------------------------------------------------------------------
+    def _on_device(self):
+        """Launches and asynchronous copies of this set go to the current stream OF ITS OWN DEVICE, whatever device
+        the caller has current (a client that drives towers on several GPUs)."""
+        import contextlib
+
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
     def _fill(self, index: int):
         """Next permutation of the generator -> buffer ``index`` (and its Gram blocks), on the current stream."""
+        with self._on_device():
+            self._fill_on_device(index)
+
+    def _fill_on_device(self, index: int):
         s = self._sets[index]
         perm = self._take_perm()
         if self.device.type == "cuda":
@@ -396,12 +407,17 @@ class DeviceDataset:
             # the host may run epochs ahead of the device: do not overwrite a permutation whose copy is still queued
             self._pin_copied[turn].synchronize()
         torch.randperm(self.num_examples, generator=self._gen, out=host)
-        self._staged_perm = host.to(self.device, non_blocking=True)
-        self._pin_copied[turn] = torch.cuda.Event()
-        self._pin_copied[turn].record(torch.cuda.current_stream(self.device))
+        with self._on_device():
+            self._staged_perm = host.to(self.device, non_blocking=True)
+            self._pin_copied[turn] = torch.cuda.Event()
+            self._pin_copied[turn].record(torch.cuda.current_stream(self.device))
 
     def _fill_gram(self, s):
         """Gram blocks of the epoch order already in ``s["x"]``."""
+        with self._on_device():
+            self._fill_gram_on_device(s)
+
+    def _fill_gram_on_device(self, s):
         nb, b = self.batches_per_epoch, self.batch_size
         if nb < 2:
             return

@@ -113,7 +113,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_sum_apply.argtypes = [vp, vp, i32, i64, vp, f32, vp, vp]
     lib.dtf_sum_apply.restype = C.c_int
     lib.dtf_philox_normal.argtypes = [vp, i64, u64, u64, f32, f32, vp]
-    lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.dtf_gather_rows.argtypes = [vp, vp, vp, i64, i32, i64, vp, vp]
     lib.dtf_hip_build_info.restype = C.c_char_p
     lib.dtf_gather_gram_supported.argtypes = [i32, i32]
     lib.dtf_gather_gram_supported.restype = C.c_int
@@ -547,17 +547,53 @@ def philox_normal_(out, seed: int, offset: int = 0, mean: float = 0.0, stddev: f
     return out
 
 
+_gather_err = {}
+
+
+def _gather_err_word(device: torch.device) -> torch.Tensor:
+    """Two ints per device: how many row indices a gather found outside its source, and where the first one sat."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _gather_err.get(key)
+    if t is None and not torch.cuda.is_current_stream_capturing():
+        # (never allocated inside a stream capture: the word has to outlive every graph that holds its address)
+        t = _gather_err[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t
+
+
+def gather_errors(device=None) -> int:
+    """Number of out-of-range row indices the gathers on ``device`` have clamped so far (synchronises).  Anything but
+    0 means a permutation was corrupted or read before it had arrived: the caller should stop trusting the data set."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _gather_err.get(key)
+    return 0 if t is None else int(t[0].item())
+
+
+def reset_gather_errors(device=None) -> None:
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key in _gather_err:
+        _gather_err[key].zero_()
+
+
 def gather_rows(src, idx, out: Optional[torch.Tensor] = None):
     lib = require()
     _f32c(src, "src")
     if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
         raise HipKernelError("gather_rows: idx must be contiguous int64 CUDA tensor")
+    if idx.device != src.device:
+        raise HipKernelError(f"gather_rows: idx on {idx.device}, src on {src.device}")
     rows, cols = idx.numel(), src.shape[1]
     if out is None:
         out = torch.empty((rows, cols), device=src.device, dtype=torch.float32)
-    if out.shape[0] < rows or out.shape[1] != cols:
+    if out.shape[0] < rows or out.shape[1] != cols or out.device != src.device:
         raise HipKernelError("gather_rows: bad output shape")
-    _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, _stream()), "dtf_gather_rows")
+    if torch.cuda.current_device() != src.device.index:
+        raise HipKernelError(f"gather_rows: launched with cuda:{torch.cuda.current_device()} current on tensors of "
+                             f"{src.device} (the launch would go to another device's stream)")
+    err = _gather_err_word(src.device)
+    _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, src.shape[0], _ptr(err), _stream()),
+           "dtf_gather_rows")
     return out
 
 
@@ -585,6 +621,9 @@ def gather_gram(src, perm, dst, gram, B: int, nb: int, ysrc=None, ydst=None):
         C_ = ysrc.shape[1]
         if ysrc.shape[0] != src.shape[0] or ydst.shape[1] != C_ or ydst.shape[0] < nb * B:
             raise HipKernelError("gather_gram: label shape mismatch")
+    if perm.device != src.device or gram.device != src.device or torch.cuda.current_device() != src.device.index:
+        raise HipKernelError(f"gather_gram: tensors on {src.device} / {perm.device} / {gram.device}, launched with "
+                             f"cuda:{torch.cuda.current_device()} current")
     _check(lib.dtf_gather_gram(_ptr(src), _ptr(perm), _ptr(dst), _ptr(gram), src.shape[0], int(B), K, int(nb),
                                gram.shape[2], _ptr(ysrc) if ydst is not None else None, _ptr(ydst), C_, _stream()),
            "dtf_gather_gram")

@@ -351,18 +351,54 @@ class InGraphEngine:
                 f"tower, gradient mean inside the towers' backward launches (words stored into the other towers' "
                 f"inboxes through peer access), 2 launches/step, 1 host call per tower per chunk")
 
+    def _check_streams(self):
+        """Towers that share a GPU wait for each other inside their kernels: their streams must (still) sit on
+        different hardware queues.  Checked at creation and again before every capture."""
+        for a in range(self.n):
+            for b in range(a + 1, self.n):
+                if self.devices[a] == self.devices[b]:
+                    with torch.cuda.device(self.devices[a]):
+                        if not hb.streams_independent(self.streams[a], self.streams[b]):
+                            raise RuntimeError(f"towers {a} and {b} on {self.devices[a]}: streams "
+                                               f"{self.streams[a].cuda_stream:#x} / {self.streams[b].cuda_stream:#x} "
+                                               f"share a hardware queue")
+
+    def diagnostics(self) -> dict:
+        """Stream handles, inbox addresses and, after a failed exchange, every tower's record of it."""
+        if self._loop is not None:
+            return {}
+        self.synchronize()
+        return {"streams": [hex(s.cuda_stream) for s in self.streams],
+                "spare_streams": [hex(s.cuda_stream) for s in self._spare_streams],
+                "inboxes": [hex(tr.xg._ptr) for tr in self.towers],
+                "states": [hex(tr.xg.state.data_ptr()) for tr in self.towers],
+                "exchanges": [tr.xg.exchanges_done() for tr in self.towers],
+                "failed": [tr.xg.diagnose() for tr in self.towers],
+                "gather_errors": [hb.gather_errors(d) for d in sorted(set(self.devices), key=str)]}
+
     # -- capture: the towers' warm-up exchanges have to be in flight TOGETHER --------------------------
     def _capture_all(self, pos: int, k: int, parity: int):
         tw = self.towers
+        self._check_streams()
         snaps = []
         for t, tr in enumerate(tw):
             with self._on(t):
                 snaps.append(tr._snapshot())
                 tr.engine.reset_step_workspace(parity)
-        for _ in range(2):                        # real exchanges among all towers, rolled back below
+        import os
+        debug = os.environ.get("DTF_TOWERS_DEBUG") == "1"
+        for w in range(2):                        # real exchanges among all towers, rolled back below
+            before = [tr.xg.exchanges_done() for tr in tw] if debug else None
             for t, tr in enumerate(tw):
                 with self._on(t):
                     tr._one_step(pos)
+            if debug:
+                self.synchronize()
+                after = [tr.xg.exchanges_done() for tr in tw]
+                bad = [tr.xg.failed() for tr in tw]
+                if any(bad) or any(a != b + 1 for a, b in zip(after, before)):
+                    print(f"[towers debug] capture ({pos},{k},{parity}) warm-up {w}: exchange numbers {before} -> {after}, "
+                          f"failed {bad}, raw state {[tr.xg.state.cpu().tolist() for tr in tw]}", flush=True)
         self.synchronize()
         for t, tr in enumerate(tw):
             with self._on(t):

@@ -39,10 +39,53 @@ class _DeviceBuffer:
                                          "data": (ptr, False), "version": 2, "strides": None}
 
 
-def _alloc(nbytes: int, uncached: bool) -> int:
+# ---- exchange memory lives as long as the process ------------------------------------------------------------------
+# Exchange buffers (inboxes, gradient slabs, flag arrays, parameter-server shards) are taken from a pool that never
+# gives memory back to the driver, and mappings of other processes' buffers are kept open and reused.  Freeing and
+# re-allocating such buffers while a process goes on building engines is what the pool rules out: on this
+# platform (MI355X, ROCm 7.2, SPX) a process that had freed and re-allocated uncached exchange buffers a few times
+# ended up with ONE of the eight XCDs reading other values than the remaining seven (and than the host) from
+# ordinary device memory allocated afterwards, across kernel boundaries -- the exchange number of a tower, then
+# parameters, finally a permutation.  bench/stress/ingraph_identity.py is the reproducer (variant "free": the old
+# behaviour); with the pool twelve rounds of two engines each stay bit-identical.
+_pool_free: dict = {}       # (device index, bytes, uncached) -> [address, ...]
+_pool_all: dict = {}        # address -> (device index, bytes, uncached)
+_pool_enabled = True        # the stress test's "free" variant switches it off to show the failure
+
+
+def _alloc(nbytes: int, uncached: bool, fill: int = 0) -> int:
+    """``nbytes`` of device memory on the current device, every byte set to ``fill``."""
+    lib = hb.require()
+    key = (torch.cuda.current_device(), int(nbytes), bool(uncached))
+    free = _pool_free.get(key)
+    if _pool_enabled and free:
+        ptr = free.pop()
+        hb._check(lib.dtf_xgmi_fill(ptr, int(fill) & 0xFF, int(nbytes)), "dtf_xgmi_fill")
+        return ptr
     out = C.c_void_p()
-    hb._check(hb.require().dtf_xgmi_alloc(C.byref(out), int(nbytes), int(uncached)), "dtf_xgmi_alloc")
-    return int(out.value)
+    hb._check(lib.dtf_xgmi_alloc(C.byref(out), int(nbytes), int(uncached)), "dtf_xgmi_alloc")
+    ptr = int(out.value)
+    if fill:
+        hb._check(lib.dtf_xgmi_fill(ptr, int(fill) & 0xFF, int(nbytes)), "dtf_xgmi_fill")
+    _pool_all[ptr] = key
+    return ptr
+
+
+def _release(ptr: int) -> None:
+    """Back into the pool (the memory stays allocated and mapped; the next taker re-fills it)."""
+    if not ptr:
+        return
+    key = _pool_all.get(ptr)
+    if key is None:
+        return
+    if not _pool_enabled:
+        del _pool_all[ptr]
+        with torch.cuda.device(key[0]):
+            hb.require().dtf_xgmi_free(ptr)
+        return
+    free = _pool_free.setdefault(key, [])
+    if ptr not in free:
+        free.append(ptr)
 
 
 def _export(ptr: int) -> bytes:
@@ -51,10 +94,28 @@ def _export(ptr: int) -> bytes:
     return buf.raw
 
 
+_opened: dict = {}          # (device index, handle bytes) -> [address, users]
+
+
 def _open(handle: bytes) -> int:
+    """Map another process's buffer; a handle this process has mapped before resolves to the mapping it has."""
+    key = (torch.cuda.current_device(), bytes(handle))
+    hit = _opened.get(key)
+    if hit is not None:
+        hit[1] += 1
+        return hit[0]
     out = C.c_void_p()
     hb._check(hb.require().dtf_xgmi_open(C.create_string_buffer(handle, HANDLE_BYTES), C.byref(out)), "dtf_xgmi_open")
+    _opened[key] = [int(out.value), 1]
     return int(out.value)
+
+
+def _close(ptr: int) -> None:
+    """Drop one use of a mapping.  The mapping itself stays (see the note on the pool above)."""
+    for hit in _opened.values():
+        if hit[0] == ptr and hit[1] > 0:
+            hit[1] -= 1
+            return
 
 
 def _encode(obj) -> bytes:
@@ -277,10 +338,10 @@ class XgmiExchange:
             pass
         with torch.cuda.device(self.device):
             for p in self._mapped:
-                lib.dtf_xgmi_close(p)
+                _close(p)
             self.grads = []
-            lib.dtf_xgmi_free(self._grad_ptr)
-            lib.dtf_xgmi_free(self._flag_ptr)
+            _release(self._grad_ptr)
+            _release(self._flag_ptr)
 
     def __del__(self):
         try:
@@ -414,9 +475,9 @@ class PeerShards:
             pass
         with torch.cuda.device(self.device):
             for p in self._mapped:
-                lib.dtf_xgmi_close(p)
+                _close(p)
             self.buffer = None
-            lib.dtf_xgmi_free(self._ptr)
+            _release(self._ptr)
 
     def __del__(self):
         try:
@@ -457,12 +518,11 @@ class PeerInbox:
 
         def local():
             with torch.cuda.device(self.device):
-                self._ptr = _alloc(2 * self.slot_bytes, True)
-                if self.compact:
-                    hb._check(lib.dtf_xgmi_fill(self._ptr, 0xFF, 2 * self.slot_bytes), "dtf_xgmi_fill")
+                self._ptr = _alloc(2 * self.slot_bytes, True, fill=0xFF if self.compact else 0)
                 # [0]: number of the current exchange, bumped by every forward launch (so numbers start at 1 and
-                # an empty inbox, all zeros, never matches), [2]: error
-                self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+                # an empty inbox, all zeros, never matches), [2]: error, [3..12]: who gave up waiting for whom
+                # (xg_report_timeout in csrc/mlp_step2.hip, read by diagnose())
+                self.state = torch.zeros(16, dtype=torch.int32, device=self.device)
                 return {"rank": self.rank, "bytes": self.slot_bytes + (1 if self.two_phase else 0),   # (variant tag)
                         "handle": _export(self._ptr) if (self.world > 1 and connect) else b""}
 
@@ -519,6 +579,28 @@ class PeerInbox:
     def exchanges_done(self) -> int:
         return int(self.state[0].item())
 
+    def diagnose(self) -> Optional[dict]:
+        """After a failed exchange: the record of the first thread that gave up (which workgroup and thread, which
+        peer's word was missing for which element of which exchange, what the word held instead), how many threads
+        gave up, and what that word of the inbox holds NOW in both slots (a word that has arrived meanwhile means a
+        peer that was late, not one that never sent).  None while nothing has failed."""
+        st = [int(v) & 0xFFFFFFFF for v in self.state.cpu().tolist()]
+        if not st[2]:
+            return None
+        rec = {"rank": self.rank, "exchanges_started": st[0], "threads_gave_up": st[12], "workgroup": st[4],
+               "thread": st[5], "waiting_for_rank": st[6] if st[6] < self.world else -1, "exchange": st[7],
+               "word_seen": (st[8], st[9]), "element": st[10], "inbox": hex(self._ptr)}
+        peer, e = rec["waiting_for_rank"], st[10]
+        if 0 <= peer < self.world and e < self.numel:
+            width = 4 if self.compact else 8
+            now = []
+            for slot in (0, 1):
+                addr = self._ptr + slot * self.slot_bytes + (peer * self.numel + e) * width
+                view = torch.as_tensor(_DeviceBuffer(addr, width, "<i4", 4, False), device=self.device)
+                now.append(tuple(int(v) & 0xFFFFFFFF for v in view.cpu().tolist()))
+            rec["word_now_slot0"], rec["word_now_slot1"] = now     # 8-byte words: (value bits, exchange number)
+        return rec
+
     def close(self):
         if self._closed:
             return
@@ -530,8 +612,8 @@ class PeerInbox:
             pass
         with torch.cuda.device(self.device):
             for p in self._mapped:
-                lib.dtf_xgmi_close(p)
-            lib.dtf_xgmi_free(self._ptr)
+                _close(p)
+            _release(self._ptr)
 
     def __del__(self):
         try:
