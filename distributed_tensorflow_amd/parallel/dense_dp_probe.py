@@ -186,7 +186,10 @@ def main(argv=None) -> int:
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer
-        out = {"error": f"{type(e).__name__}: {e}"}
+        if "with_collectives" in out:      # the measurement is complete: a late failure (the last barrier,
+            out = dict(out, late_error=f"{type(e).__name__}: {e}")     # tearing down the group) must not cost it
+        else:
+            out = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     return 0 if "error" not in out else 3
 

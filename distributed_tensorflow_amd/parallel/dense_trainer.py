@@ -486,6 +486,7 @@ class PsDenseSyncResidentTrainer:
         self.params = sess.theta
         self.store.pull(self.params)                 # every replica starts from the chief's initial values
         torch.cuda.synchronize(self.device)
+        sess.own_replica(self)                       # from here to publish() / close() the shards lag behind
         self.global_step = layout.view(self.params, "global_step").view(1)
         view = lambda slab, v: None if v is None else layout.view(slab, v.op_name)  # noqa: E731
         group = StoreGroup(sess.server.client("ps", 0), "dense-sync-resident", self.rank, self.world)
@@ -577,3 +578,5 @@ class PsDenseSyncResidentTrainer:
     def close(self):
         self._graphs.clear()
         self.xg.close()
+        if self.sess._replica_owner is self:
+            self.sess.own_replica(None)

@@ -253,6 +253,7 @@ class PsSyncResidentTrainer(_BaseTrainer):
         self.params, self.grads = sess.theta, None
         self.store.pull(self.params)                 # every replica starts from the chief's initial values
         torch.cuda.synchronize(self.device)
+        sess.own_replica(self)                       # from here to publish() / close() the shards lag behind
         names = {r: m[r].op_name for r in ("W1", "b1", "W2", "b2")}
         self.global_step = self.layout.view(self.params, "global_step").view(1)
         self.engine = MLPEngine({r: self.layout.view(self.params, n) for r, n in names.items()}, None,
@@ -328,6 +329,8 @@ class PsSyncResidentTrainer(_BaseTrainer):
     def close(self):
         self._graphs.clear()
         self.xg.close()
+        if self.sess._replica_owner is self:
+            self.sess.own_replica(None)
 
     def describe(self) -> str:
         how = ("exchange inside the backward launch over peer-mapped HBM" if self.exchange == "inbox" else

@@ -199,6 +199,7 @@ class Session:
         self.grad = self.layout.new_slab(self.device)
         self._engines: Dict[Any, MLPEngine] = {}
         self._plans: Dict[int, Any] = {}
+        self._replica_owner = None
         self._closed = False
         self.fused_steps = 0
         self._local_step_ready = False
@@ -282,8 +283,17 @@ class Session:
         return self.layout.view(self.theta, v.op_name)
 
     def _pull(self):
+        # A device-resident synchronous trainer keeps THE replica of this worker in self.theta and only publishes it to
+        # the parameter-server shards at the end (``own_replica``): until then the shards hold older values, and a pull
+        # (a checkpoint of the Supervisor's thread, an evaluation) would silently set this worker back.
+        if self._replica_owner is not None:
+            return
         with self.run_lock, span("pull"):
             self.store.pull(self.theta)
+
+    def own_replica(self, owner) -> None:
+        """``owner`` (a trainer) declares self.theta authoritative for this worker; ``None`` hands it back."""
+        self._replica_owner = owner
 
     def _run_init(self, variables: Sequence[G.Variable]):
         self._gs_mirror = None

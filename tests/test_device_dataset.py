@@ -52,3 +52,36 @@ def test_double_buffer_is_ignored_on_the_cpu():
     x, y = _data()
     ds = DeviceDataset(x, y, "cpu", 100, seed=1, double_buffer=True)
     assert not ds.double_buffer and ds.active == 0 and ds.set_tensors(0)[0] is ds.x_epoch
+
+
+def test_launches_of_a_set_go_to_its_own_device_whatever_device_is_current(monkeypatch):
+    """A single client that drives towers on several GPUs calls `shuffle_epoch()` with some other device current: the
+    gathers and the permutation upload must still be issued with the set's device current (their stream is resolved from
+    the current device).  Checked here by recording which device the set makes current around its work."""
+    import contextlib
+
+    import numpy as np
+    import torch
+
+    from distributed_tensorflow_amd.data import DeviceDataset
+
+    rng = np.random.RandomState(0)
+    ds = DeviceDataset(rng.rand(40, 8).astype(np.float32), np.eye(4, dtype=np.float32)[rng.randint(0, 4, 40)], "cpu", 10)
+    assert isinstance(ds._on_device(), contextlib.nullcontext)
+    seen = []
+
+    class FakeDeviceGuard:
+        def __init__(self, device):
+            seen.append(torch.device(device))
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "device", FakeDeviceGuard)
+    ds.device = torch.device("cuda", 3)           # (pretend: only the guard is exercised, no launch is made)
+    with ds._on_device():
+        pass
+    assert seen == [torch.device("cuda", 3)]

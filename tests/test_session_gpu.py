@@ -216,6 +216,39 @@ def test_resident_sync_workers_of_a_deeper_stack_stay_identical(n_ps, n_w, trans
     assert all(c[-1] < c[0] for c in costs)
 
 
+def test_checkpoints_during_a_resident_sync_run_save_the_replica_and_leave_it_alone(tmp_path):
+    """tfdist_between_sync.py --resident --hidden 64,32 with a checkpoint every 0.2 s: while the trainer is attached
+    the parameter-server shards still hold the initial values, so a save that pulled them would write a stale
+    checkpoint AND set the chief's replica back (the workers would then differ).  The save must read the replica."""
+    import re
+
+    from cluster_utils import launch_script
+
+    from distributed_tensorflow_amd.train.saver import latest_checkpoint, read_bundle
+
+    logdir = tmp_path / "ckpt"
+    args = ["--epochs=6", "--train_size=2200", "--freq=11", "--lr=0.05", "--transport=ipc", "--resident",
+            "--hidden=64,32", "--activation=relu", f"--logs_path={tmp_path}", f"--logdir={logdir}",
+            "--save_model_secs=0.2"]
+    res = launch_script("tfdist_between_sync.py", 1, 2, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    accs, costs = [], []
+    for i in range(2):
+        out = res[f"worker{i}"][1]
+        assert out.rstrip().endswith("Done")
+        accs.append(re.findall(r"Test-Accuracy: ([\d.]+)", out))
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+    assert accs[0] == accs[1] and len(accs[0]) == 6          # the chief was never set back: replicas stayed identical
+    assert all(c[-1] < c[0] for c in costs)
+    last = latest_checkpoint(str(logdir))
+    assert last is not None
+    saved = read_bundle(last)
+    step = int(round(float(saved["global_step"])))
+    assert 0 < step <= 6 * 22                                 # a checkpoint of the TRAINED replica, not of the stale shards
+    assert last.endswith(f"-{step}")
+
+
 @pytest.mark.timeout(300)
 def test_more_resident_sync_workers_than_one_gpu_can_keep_spinning_use_the_bounded_exchange(tmp_path):
     """1 ps + 4 synchronous workers, all on the one GPU (the reference's scenario 2 with more workers): their

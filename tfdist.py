@@ -61,6 +61,14 @@ def main(_):
     mnist_mlp.run_resident_loop(towers, mnist, FLAGS, writer, begin_time)
     if writer is not None:
         writer.close()
+    # towers apply the same mean gradient, so their replicas must be the same bits; an exchange that gave up waiting
+    # (skipping its update from then on) or replicas that differ void the run instead of passing silently
+    healthy = towers.healthy() if hasattr(towers, "healthy") else True
+    if not healthy or not towers.replicas_identical():
+        detail = towers.diagnostics() if hasattr(towers, "diagnostics") else {}
+        raise RuntimeError(f"in-graph towers out of step (healthy={healthy}): {detail}")
+    if hasattr(towers, "close"):
+        towers.close()
     print("Done")
     return 0
 
