@@ -17,7 +17,7 @@ x = torch.rand(55000, 784, generator=g)
 y = torch.eye(10)[torch.randint(0, 10, (55000,), generator=g)]
 ds = DeviceDataset(x, y, dev, 100, seed=1)
 for mode, extra in (("single", {"pipelined": True}), ("single", {"pipelined": False}), ("towers", {}), ("xgmi", {}),
-                    ("xgmi2", {}), ("xgmi2c", {}), ("xgmi_async", {})):
+                    ("xgmi2", {}), ("xgmi2c", {}), ("xgmi2p", {}), ("xgmi_async", {})):
     t = build_replica_trainer(mode, device=dev, dataset=ds, batch=100, lr=0.001, seed=1, rank=0, world=1, chunk=50,
                               use_graph=True, **extra)
     t.prepare((550, steps))

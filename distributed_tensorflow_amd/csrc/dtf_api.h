@@ -156,14 +156,21 @@ typedef struct DtfXgDesc {
   int32_t compact;                      // dtf_mlp_step_xg: 1 = inbox words are bare 4-byte values, unwritten ones hold
                                         // 0xffffffff (the inbox must be filled with that pattern beforehand);
                                         // 2 = two-phase exchange (8-byte words): partials go to the element's owner,
-                                        // which returns the new parameter value to every peer
+                                        // which returns the new parameter value to every peer;
+                                        // dtf_mlp_step_async: 1 = the forward reads the variables from the shards
+                                        // themselves (no pull launch before the step; DTF_ERR_UNSUPPORTED when
+                                        // shards inside the variables are shorter than 32 rows of W1)
   int64_t step_index;                   // dtf_mlp_step_async only: element that holds global_step (< 0: none)
   int64_t shard_start[DTF_XGMI_MAX_RANKS + 1];   // dtf_mlp_step_async with n == 0: slab range of every shard
+  float* w1t;                           // dtf_mlp_step_xg only, may be null: [hidden][in_dim] image of W1 TRANSPOSED that
+                                        // the step reads and updates INSTEAD of W1 (the caller transposes W1 into it
+                                        // before the first step of a chunk and back after the last: dtf_transpose)
 } DtfXgDesc;
 // Asynchronous worker step: the backward pushes `shard_owner(e)[e] -= lr * g` with float atomics through the
 // mappings and counts the push.  n > 0: equal shards of n floats, inbox[k] = base of rank k's slab-sized buffer;
 // n == 0: shard k = slab elements [shard_start[k], shard_start[k+1]), inbox[k] = address of its first element.
 int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream);
+int dtf_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
                     void* stream);
 

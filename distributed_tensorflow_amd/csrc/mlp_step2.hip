@@ -97,6 +97,11 @@ struct BlockStamps {
   } while (0)
 
 constexpr int kFwdWaves = 16;
+// waves per workgroup of the 8x8-tile forward kernels: each wave contracts 32 k per slot
+#ifndef DTF_FWD8_WAVES
+#define DTF_FWD8_WAVES 16
+#endif
+constexpr int kFwd8Waves = DTF_FWD8_WAVES;
 constexpr int kFwdMaxMs = 4;  // macro-steps per wave held in registers (K <= 1024)
 
 __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
@@ -200,6 +205,49 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
   DTF_BLOCK_STAMP(bs, 1);
 }
 
+// ---- variables read where they LIVE: the forward of an asynchronous worker without a pull launch in front of it -----
+// An asynchronous parameter-server worker used to copy every shard into a private slab (one launch, ~3.7 us) and then
+// run forward and backward on the copy.  The forward is the only reader of W1 and b1, and the backward only needs the
+// W2 / b2 that the forward's duty workgroup snapshots into the shadow copy anyway, so the forward can read the shards
+// themselves through the peer / IPC mappings: the worker's step is two launches and the variables are still read
+// once per step (the reference pulls every variable once per sess.run, tfdist_between.py:56-58).
+// Shard k holds the slab elements [start[k], start[k+1]); base[k] is the address slab element 0 WOULD have in its
+// buffer.  A wave's 32 rows of a W1 column tile, a tile's bias and W2 elements are contiguous ranges of the slab that
+// meet at most ONE shard boundary (the host checks the shard sizes), so the owner is looked up for the two ends of
+// the range with scalar compares and a lane picks one of two bases with a single compare.
+struct ShardView {
+  const float* base[DTF_XGMI_MAX_RANKS];
+  unsigned start[DTF_XGMI_MAX_RANKS];     // ascending; 0xffffffff beyond the last shard
+  unsigned offW1, offb1, offW2, offb2;    // slab offsets of the variables
+};
+
+template <int MAXW>
+__device__ __forceinline__ void shard_pair(const ShardView& v, unsigned e_lo, unsigned e_hi, const float*& lo,
+                                           const float*& hi, unsigned& cut) {
+  lo = v.base[0];
+  hi = v.base[0];
+  cut = 0u;
+#pragma unroll
+  for (int k = 1; k < MAXW; ++k) {
+    const unsigned st = v.start[k];
+    lo = e_lo >= st ? v.base[k] : lo;
+    const bool h = e_hi >= st;
+    hi = h ? v.base[k] : hi;
+    cut = h ? st : cut;
+  }
+}
+__device__ __forceinline__ float shard_ld(const float* lo, const float* hi, unsigned cut, unsigned e) {
+  return (e >= cut ? hi : lo)[e];
+}
+// one element, any owner (the duty workgroup's snapshot of W2 / b2)
+template <int MAXW>
+__device__ __forceinline__ float shard_ld_any(const ShardView& v, unsigned e) {
+  const float* p = v.base[0];
+#pragma unroll
+  for (int k = 1; k < MAXW; ++k) p = e >= v.start[k] ? v.base[k] : p;
+  return p[e];
+}
+
 // Forward with 8x8 output tiles: twice the workgroups in each direction (13 x 13 = 169 for
 // 100 x 100), each ingesting half as many rows of x and half as many columns of W: 2 x 25 KB
 // instead of 2 x 50 KB.  A CU ingests a cold stream at only 40-60 GB/s, so the bytes per
@@ -212,13 +260,18 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile16_kernel(
 // terms and are ignored), so every loaded element is used and no lane loads padding.
 // Lane (i = l & 15, q = l >> 4): r = i & 7, g = i >> 3; slot j of wave w contracts macro-step
 // ms = 2 (w + 16 j) + g, k = 16 ms + 4 q + s for MFMA s (one 16-B load of x per slot).
-template <int NS>
-__global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
+// MAXW > 0: W / b / W2 / b2 are not used; the variables are read from the parameter-server shards of `sv` (at most
+// MAXW of them), see ShardView.
+// WT: `W` is W1 TRANSPOSED ([H][K]): the 8 columns of a tile are 8 contiguous rows of it and a lane's four k one
+// 16-byte load (instead of four 4-byte loads from four rows of W1[K][H]).
+template <int NS, int MAXW = 0, bool WT = false>
+__device__ __forceinline__ void fwd_tile8_body(
     const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
     const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
     float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
     int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs,
-    unsigned* __restrict__ exchange_counter) {
+    unsigned* __restrict__ exchange_counter, const ShardView* sv) {
+  constexpr bool SH = MAXW > 0;
   // The last grid row holds no tile: its first workgroup refreshes the shadow copy of W2/b2 and
   // clears the other logit accumulator, beside the tiles instead of at the tail of one of them.
   // For the cross-replica backward of the SAME step it also numbers the exchange: one writer, in a launch
@@ -227,14 +280,20 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
     if (blockIdx.x == 0) {
       if (exchange_counter && threadIdx.x == 0) *exchange_counter += 1u;
       const int hcw = H * C;
-      if (shadow_dst)
-        for (int e = threadIdx.x; e < hcw + C; e += kFwdWaves * 64) shadow_dst[e] = e < hcw ? W2[e] : b2[e - hcw];
-      for (int e = threadIdx.x; e < zacc_n; e += kFwdWaves * 64) zacc_other[e] = 0.f;
+      if (shadow_dst) {
+        if constexpr (SH) {
+          for (int e = threadIdx.x; e < hcw + C; e += kFwd8Waves * 64)
+            shadow_dst[e] = shard_ld_any<MAXW>(*sv, e < hcw ? sv->offW2 + e : sv->offb2 + (e - hcw));
+        } else {
+          for (int e = threadIdx.x; e < hcw + C; e += kFwd8Waves * 64) shadow_dst[e] = e < hcw ? W2[e] : b2[e - hcw];
+        }
+      }
+      for (int e = threadIdx.x; e < zacc_n; e += kFwd8Waves * 64) zacc_other[e] = 0.f;
     }
     return;
   }
   DTF_BLOCK_STAMP(bs, 0);
-  __shared__ float red[kFwdWaves][4][64];
+  __shared__ float red[kFwd8Waves][4][64];
   __shared__ float psum[2][64];
   __shared__ float a2t[8][9];
   __shared__ float w2t[64][17];   // rows >= 8 are written (never read) so that the W2 load is used by every thread
@@ -253,17 +312,33 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
   bool kok[NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    const unsigned kb = (2u * (wave + j * kFwdWaves) + g) * 16u + q * 4u;
+    const unsigned kb = (2u * (wave + j * kFwd8Waves) + g) * 16u + q * 4u;
     kok[j] = kb < (unsigned)K;                       // K % 4 == 0: a quarter is inside or outside as a whole
     const unsigned kbc = kok[j] ? kb : K - 4;
     xo[j] = (__umul24(row_c, K) + kbc) * 4u;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wo[j][s] = (__umul24(kbc + s, H) + col_c) * 4u;
+    for (int s = 0; s < 4; ++s) wo[j][s] = WT ? (__umul24(col_c, K) + kbc + s) * 4u : (__umul24(kbc + s, H) + col_c) * 4u;
   }
   const unsigned bo = umin_(col, H - 1) * 4u;          // bias of this lane's column
   const int w_h = threadIdx.x >> 4, w_c = threadIdx.x & 15;           // threads < 128: W2 tile element
   const bool w2_ok = w_h < 8 && n0 + w_h < H && w_c < C;
   const unsigned w2o = umin_(__umul24(n0 + (w_h & 7), C) + w_c, (unsigned)H * C - 1) * 4u;
+  // variables in shards: the two candidate owners of each contiguous range this wave reads (wave-uniform: scalar code)
+  const float *w_lo[NS], *w_hi[NS], *b_lo = nullptr, *b_hi = nullptr, *v_lo = nullptr, *v_hi = nullptr;
+  unsigned w_cut[NS], b_cut = 0u, v_cut = 0u;
+  if constexpr (SH) {
+    const unsigned uwave = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    const unsigned last = sv->offW1 + (unsigned)K * H - 1;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const unsigned k_first = 32u * (uwave + j * kFwd8Waves);        // rows k_first .. k_first + 31, columns n0 .. n0 + 7
+      shard_pair<MAXW>(*sv, umin_(sv->offW1 + k_first * H + n0, last), umin_(sv->offW1 + (k_first + 31u) * H + n0 + 7u, last),
+                       w_lo[j], w_hi[j], w_cut[j]);
+    }
+    shard_pair<MAXW>(*sv, sv->offb1 + umin_(n0, H - 1), sv->offb1 + umin_(n0 + 7, H - 1), b_lo, b_hi, b_cut);
+    shard_pair<MAXW>(*sv, sv->offW2 + umin_(n0 * C, H * C - 1), sv->offW2 + umin_((n0 + 7) * C + 15, H * C - 1), v_lo, v_hi,
+                     v_cut);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- loads, back to back ------------------------------------------------------------------
@@ -273,11 +348,32 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
   for (int j = 0; j < NS; ++j) {
     a[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(X) + xo[j]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bv[j][s] = ld_ub(W, wo[j][s]);
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (SH) {
+        // (a k beyond K is clamped to the last rows of W1 by wo[]: bring it back into this wave's own range, whose two
+        // owners are known; the value is masked below either way)
+        const unsigned e = kok[j] ? sv->offW1 + (wo[j][s] >> 2) : umin_(sv->offW1 + 32u * (wave + j * kFwd8Waves) * H + n0,
+                                                                        sv->offW1 + (unsigned)K * H - 1);
+        bv[j][s] = shard_ld(w_lo[j], w_hi[j], w_cut[j], e);
+      } else if constexpr (!WT) {
+        bv[j][s] = ld_ub(W, wo[j][s]);
+      }
+    }
+    if constexpr (WT && !SH) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(W) + wo[j][0]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[j][s] = w4[s];
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
-  const float bias = ld_ub(b, bo);
-  const float w2raw = ld_ub(W2, w2o);
+  float bias, w2raw;
+  if constexpr (SH) {
+    bias = shard_ld(b_lo, b_hi, b_cut, sv->offb1 + (bo >> 2));
+    w2raw = shard_ld(v_lo, v_hi, v_cut, sv->offW2 + (w2o >> 2));
+  } else {
+    bias = ld_ub(b, bo);
+    w2raw = ld_ub(W2, w2o);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- contraction ------------------------------------------------------------------------------
@@ -304,7 +400,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
     const int rg = drow & 3, ln = ((drow >> 2) << 4) | dcol;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kFwdWaves; ++w) s += red[w][rg][ln];
+    for (int w = 0; w < kFwd8Waves; ++w) s += red[w][rg][ln];
     psum[blk][threadIdx.x & 63] = s;
   }
   __syncthreads();
@@ -329,6 +425,39 @@ __global__ __launch_bounds__(kFwdWaves * 64) void fwd_tile8_kernel(
     }
   }
   DTF_BLOCK_STAMP(bs, 1);
+}
+
+template <int NS>
+__global__ __launch_bounds__(kFwd8Waves * 64) void fwd_tile8_kernel(
+    const float* __restrict__ xbase, long batch_index, const float* __restrict__ W,
+    const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
+    float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs,
+    unsigned* __restrict__ exchange_counter) {
+  fwd_tile8_body<NS, 0>(xbase, batch_index, W, b, W2, out, zacc, zacc_other, zacc_n, M, K, H, C, act, shadow_dst, b2, bs,
+                        exchange_counter, nullptr);
+}
+
+// The same forward reading W1 transposed (kept by the backward of the cross-replica step between the ends of a chunk).
+template <int NS>
+__global__ __launch_bounds__(kFwd8Waves * 64) void fwd_tile8_wt_kernel(
+    const float* __restrict__ xbase, long batch_index, const float* __restrict__ W1T,
+    const float* __restrict__ b, const float* __restrict__ W2, float* __restrict__ out,
+    float* __restrict__ zacc, float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C,
+    int act, float* __restrict__ shadow_dst, const float* __restrict__ b2, BlockStamps bs,
+    unsigned* __restrict__ exchange_counter) {
+  fwd_tile8_body<NS, 0, true>(xbase, batch_index, W1T, b, W2, out, zacc, zacc_other, zacc_n, M, K, H, C, act, shadow_dst,
+                              b2, bs, exchange_counter, nullptr);
+}
+
+// The same forward with the variables read from the parameter-server shards (see ShardView).
+template <int NS, int MAXW>
+__global__ __launch_bounds__(kFwd8Waves * 64) void fwd_tile8_shards_kernel(
+    const float* __restrict__ xbase, long batch_index, float* __restrict__ out, float* __restrict__ zacc,
+    float* __restrict__ zacc_other, int zacc_n, int M, int K, int H, int C, int act, float* __restrict__ shadow_dst,
+    BlockStamps bs, ShardView sv) {
+  fwd_tile8_body<NS, MAXW>(xbase, batch_index, nullptr, nullptr, nullptr, out, zacc, zacc_other, zacc_n, M, K, H, C, act,
+                           shadow_dst, nullptr, bs, nullptr, &sv);
 }
 
 // ---------------------------------------------------------------------------
@@ -868,7 +997,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
   // With W1 transposed the map is chosen so that 16 consecutive threads hold 16 consecutive k of one column (64
   // contiguous bytes of a W1T row) and the 64 threads of a wave four neighbouring columns (out_map).
   constexpr int kOuts = (256 * NA + kBwdThreads - 1) / kBwdThreads;
-  const bool tmap = !XG && p.rW1T != nullptr;
+  const bool tmap = p.rW1T != nullptr;
   unsigned wo[kOuts];
 #pragma unroll
   for (int u = 0; u < kOuts; ++u) {
@@ -971,7 +1100,9 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
       static_assert(kOuts == 1, "one tile element per thread");
       {
         const int o = tid;
-        const int o_sub = o >> 8, o_reg = (o >> 6) & 3, o_ln = o & 63;
+        // (dW2 tiles keep the plain map: their old values come from the W2 tile image in LDS, indexed by it)
+        int o_sub, o_reg, o_ln;
+        out_map(o, tmap && is_main, o_sub, o_reg, o_ln);
         const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
         float s = 0.f;
 #pragma unroll
@@ -983,7 +1114,8 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
           xv[0] = o < 256 * NA && orow < K && ocol < H;
           xe[0] = xg->offW1 + e;
           xold[0] = wold[0];
-          xdst[0] = p.oW1 + e;
+          // between the ends of a chunk W1 lives transposed only: the forward of the next step reads that image
+          xdst[0] = tmap ? p.oW1T + ((long)ocol * K + orow) : p.oW1 + e;
         } else {
           const int h = h0 + o_trow;
           const long e = (long)h * C + o_tcol;
@@ -1481,7 +1613,8 @@ bool dtf_step2_supported(int B, int K, int H, int C) {
 // into; consecutive steps MUST alternate it (the other half is cleared for the
 // next step by the forward launch).
 static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
-                             hipStream_t stream, XgParams* xg, bool xg_async = false) {
+                             hipStream_t stream, XgParams* xg, bool xg_async = false, const ShardView* sv = nullptr,
+                             float* w1t = nullptr) {
   const int B = d->batch, K = d->in_dim, H = d->hidden, C = d->classes;
   if (!dtf_step2_supported(B, K, H, C)) return DTF_ERR_UNSUPPORTED;
   const bool fused = mode == DTF_HEAD_FUSED;
@@ -1495,14 +1628,51 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
 #define DTF_FWD_ARGS                                                                                   \
   dim3(tiles_n, tiles_m), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}
-  const int ns8 = ((K + 15) / 16 + 31) / 32;   // slots of the 8x8 tiling: 32 macro-steps per slot
+  const int ns8 = ((K + 15) / 16 + 2 * kFwd8Waves - 1) / (2 * kFwd8Waves);   // slots of the 8x8 tiling: two macro-steps per wave and slot
   const bool tile8 = g_fwd_tile8 && (K & 3) == 0 && K >= 16 && ns8 <= 4;
 #define DTF_FWD8_ARGS                                                                                 \
-  dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwdWaves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
+  dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwd8Waves * 64), 0, stream, d->x, batch_index, d->W1, d->b1, d->W2, d->z2, \
       zacc, zother, R * 16, B, K, H, C, d->act, fused ? d->shadow : nullptr, d->b2, BlockStamps{g_block_stamps}, \
       (xg && !xg_async ? xg->state : (unsigned*)nullptr)
   if (xg && !xg_async && !tile8) return DTF_ERR_UNSUPPORTED;   // the exchange is numbered by the 8x8 forward's duty workgroup
-  if (tile8 && ns8 == 2) {
+  if (w1t && !(xg && !xg_async && fused && tile8)) return DTF_ERR_UNSUPPORTED;
+  if (w1t) {
+    // W1 lives transposed between the ends of a chunk (dtf_transpose at both ends): the forward reads the image with
+    // 16-byte loads, the backward below updates it in place
+#define DTF_FWD8_WT(NS_)                                                                                                \
+  hipLaunchKernelGGL((fwd_tile8_wt_kernel<NS_>), dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwd8Waves * 64), 0, stream, d->x, \
+                     batch_index, w1t, d->b1, d->W2, d->z2, zacc, zother, R * 16, B, K, H, C, d->act, d->shadow, d->b2,     \
+                     BlockStamps{g_block_stamps}, xg->state)
+    if (ns8 == 1) DTF_FWD8_WT(1);
+    else if (ns8 == 2) DTF_FWD8_WT(2);
+    else if (ns8 == 3) DTF_FWD8_WT(3);
+    else DTF_FWD8_WT(4);
+#undef DTF_FWD8_WT
+  } else if (sv) {
+    // the forward reads the variables from the parameter-server shards and snapshots W2 / b2 for the backward
+    if (!tile8 || !d->shadow) return DTF_ERR_UNSUPPORTED;
+    int shards = 1;
+    for (int k = 1; k < DTF_XGMI_MAX_RANKS; ++k)
+      if (sv->start[k] != 0xffffffffu) shards = k + 1;
+#define DTF_FWD8_SH(NS_, MW_)                                                                                          \
+  hipLaunchKernelGGL((fwd_tile8_shards_kernel<NS_, MW_>), dim3((H + 7) / 8, (B + 7) / 8 + 1), dim3(kFwd8Waves * 64), 0,   \
+                     stream, d->x, batch_index, d->z2, zacc, zother, R * 16, B, K, H, C, d->act, d->shadow,              \
+                     BlockStamps{g_block_stamps}, *sv)
+#define DTF_FWD8_SH_W(NS_)                                    \
+  do {                                                        \
+    if (shards <= 1) DTF_FWD8_SH(NS_, 1);                     \
+    else if (shards <= 2) DTF_FWD8_SH(NS_, 2);                \
+    else if (shards <= 4) DTF_FWD8_SH(NS_, 4);                \
+    else if (shards <= 8) DTF_FWD8_SH(NS_, 8);                \
+    else DTF_FWD8_SH(NS_, 16);                                \
+  } while (0)
+    if (ns8 == 1) DTF_FWD8_SH_W(1);
+    else if (ns8 == 2) DTF_FWD8_SH_W(2);
+    else if (ns8 == 3) DTF_FWD8_SH_W(3);
+    else DTF_FWD8_SH_W(4);
+#undef DTF_FWD8_SH_W
+#undef DTF_FWD8_SH
+  } else if (tile8 && ns8 == 2) {
     hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_FWD8_ARGS);
   } else if (tile8 && ns8 == 1) {
     hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_FWD8_ARGS);
@@ -1521,11 +1691,11 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
   p.xbase = d->x;
   p.ybase = d->y;
   p.batch_index = batch_index;
-  p.W2r = fused ? d->shadow : d->W2;
-  p.b2r = fused ? d->shadow + H * C : d->b2;
+  p.W2r = (fused || sv) ? d->shadow : d->W2;
+  p.b2r = (fused || sv) ? d->shadow + H * C : d->b2;
   p.oW1 = fused ? d->W1 : d->gW1;
-  p.oW1T = nullptr;
-  p.rW1T = nullptr;
+  p.oW1T = w1t;
+  p.rW1T = w1t;
   p.ob1 = fused ? d->b1 : d->gb1;
   p.oW2 = fused ? d->W2 : d->gW2;
   p.ob2 = fused ? d->b2 : d->gb2;
@@ -1634,7 +1804,36 @@ extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int pari
   a.world = x->world;
   a.compact = 0;
   a.timeout_ticks = 0;
-  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true);
+  if (x->compact != 1)
+    return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true);
+  // x->compact == 1 here means: no pull in front of this step -- the forward reads the variables from the shards.
+  ShardView sv;
+  for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
+    sv.base[r] = reinterpret_cast<const float*>(a.inbox[r]);
+    sv.start[r] = a.start[r];
+    if (!sv.base[r]) {                  // an empty shard has no buffer: it owns no element, any valid address will do
+      sv.base[r] = sv.base[0];
+    }
+  }
+  sv.offW1 = (unsigned)x->offW1; sv.offb1 = (unsigned)x->offb1; sv.offW2 = (unsigned)x->offW2; sv.offb2 = (unsigned)x->offb2;
+  // A wave's range of W1 (32 rows of a column tile), a tile's bias and W2 elements must meet at most one shard
+  // boundary: every boundary inside the variables is followed by a shard of at least 32 rows of W1.
+  {
+    const long lo = x->offW1 < x->offW2 ? (x->offW1 < x->offb1 ? x->offW1 : x->offb1) : (x->offW2 < x->offb1 ? x->offW2 : x->offb1);
+    long hi = x->offW1 + K * H;
+    if (x->offb1 + H > hi) hi = x->offb1 + H;
+    if (x->offW2 + H * C > hi) hi = x->offW2 + H * C;
+    if (x->offb2 + C > hi) hi = x->offb2 + C;
+    long bounds[DTF_XGMI_MAX_RANKS + 1];
+    int nb = 0;
+    for (int r = 1; r < x->world; ++r) {
+      const long st = a.start[r];
+      if (st > lo && st < hi && (nb == 0 || bounds[nb - 1] != st)) bounds[nb++] = st;
+    }
+    for (int i = 0; i + 1 < nb; ++i)
+      if (bounds[i + 1] - bounds[i] < 32 * H + 16) return DTF_ERR_UNSUPPORTED;
+  }
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true, &sv);
 }
 
 int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,
@@ -1673,8 +1872,13 @@ extern "C" int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity,
   if (x->compact < 0 || x->compact > 2) return DTF_ERR_SHAPE;
   a.compact = x->compact;
   a.timeout_ticks = (long long)(x->timeout_ms > 0 ? x->timeout_ms : 5000) * 100000;   // 100 MHz wall clock
-  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a);
+  if (x->w1t && (reinterpret_cast<uintptr_t>(x->w1t) & 15u)) return DTF_ERR_SHAPE;
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_FUSED, grad_scale, (hipStream_t)stream, &a, false, nullptr,
+                           x->w1t);
 }
+
+// dst[c][r] = src[r][c] for a row-major [rows][cols] matrix (the two ends of a chunk that keeps W1 transposed).
+extern "C" int dtf_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 
 // Tuning / test hook: choose between the 8x8-tile forward (default) and the 16x16-tile one.
 extern "C" void dtf_debug_set_fwd_tile8(int on) { g_fwd_tile8 = on != 0; }
@@ -1706,6 +1910,14 @@ __global__ void transpose_and_zero_kernel(const float* __restrict__ src, float* 
   __syncthreads();
   for (int i = threadIdx.y; i < 32; i += 8)
     if (c0 + i < cols && r0 + threadIdx.x < rows) dst[(long)(c0 + i) * rows + r0 + threadIdx.x] = tile[threadIdx.x][i];
+}
+
+extern "C" int dtf_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
+  if (!src || !dst) return DTF_ERR_NULL;
+  if (rows < 1 || cols < 1) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_and_zero_kernel, dim3((rows + 31) / 32 + 1, (cols + 31) / 32), dim3(32, 8), 0,
+                     (hipStream_t)stream, src, dst, rows, cols, (float*)nullptr, 0);
+  return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
 __global__ void zero_floats_kernel(float* p, int n) {
@@ -1781,14 +1993,18 @@ extern "C" int dtf_mlp_chunk_pipelined_ex(const DtfMlpDesc* d, const DtfPipeDesc
       return DTF_ERR_LAUNCH;
   }
   if (!carry_in) {        // forward of the first step, from the caller's parameters
-    const int ns8 = ((K + 15) / 16 + 31) / 32;
-    const dim3 grid(tiles_n8, tiles_m8 + 1), block(kFwdWaves * 64);
+    const int ns8 = ((K + 15) / 16 + 2 * kFwd8Waves - 1) / (2 * kFwd8Waves);
+    const dim3 grid(tiles_n8, tiles_m8 + 1), block(kFwd8Waves * 64);
 #define DTF_F0_ARGS grid, block, 0, stream, d->x, fb, d->W1, d->b1, d->W2, a2buf[fb & 1], zw[fb % 3], zw[(fb + 1) % 3], \
                     R * 16, B, K, H, C, d->act, (float*)nullptr, d->b2, BlockStamps{nullptr}, (unsigned*)nullptr
     if (ns8 == 1) {
       hipLaunchKernelGGL((fwd_tile8_kernel<1>), DTF_F0_ARGS);
-    } else {
+    } else if (ns8 == 2) {
       hipLaunchKernelGGL((fwd_tile8_kernel<2>), DTF_F0_ARGS);
+    } else if (ns8 == 3) {
+      hipLaunchKernelGGL((fwd_tile8_kernel<3>), DTF_F0_ARGS);
+    } else {
+      hipLaunchKernelGGL((fwd_tile8_kernel<4>), DTF_F0_ARGS);
     }
 #undef DTF_F0_ARGS
   }

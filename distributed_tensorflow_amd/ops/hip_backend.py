@@ -92,6 +92,7 @@ class DtfXgDesc(C.Structure):
         ("compact", C.c_int32),
         ("step_index", C.c_int64),
         ("shard_start", C.c_int64 * 17),
+        ("w1t", C.c_void_p),
     ]
 
 
@@ -136,6 +137,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_push_sgd.argtypes = [vp, i32, i64, vp, vp, i64, vp]
     lib.dtf_xgmi_pull_ranges.argtypes = [vp, vp, i32, vp, vp]
     lib.dtf_xgmi_fill.argtypes = [vp, i32, i64]
+    lib.dtf_transpose.argtypes = [vp, vp, i32, i32, vp]
+    lib.dtf_transpose.restype = C.c_int
     for name in ("dtf_xgmi_pull", "dtf_xgmi_push_sgd", "dtf_xgmi_pull_ranges", "dtf_xgmi_fill",
                  "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
                  "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
@@ -677,6 +680,14 @@ def mlp_step_async(desc: DtfMlpDesc, batch_index: int, parity: int, xg: DtfXgDes
 def mlp_step_xg(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float, xg: DtfXgDesc):
     _check(require().dtf_mlp_step_xg(C.byref(desc), int(batch_index), int(parity), float(grad_scale), C.byref(xg),
                                      _stream()), "dtf_mlp_step_xg")
+
+
+def transpose(src: torch.Tensor, dst: torch.Tensor):
+    """``dst[c, r] = src[r, c]`` for contiguous float32 matrices (one launch)."""
+    _f32c(src, "src"), _f32c(dst, "dst")
+    if src.dim() != 2 or dst.shape != (src.shape[1], src.shape[0]) or dst.device != src.device:
+        raise HipKernelError("transpose: dst must be shaped like src.T on the same device")
+    _check(require().dtf_transpose(_ptr(src), _ptr(dst), src.shape[0], src.shape[1], _stream()), "dtf_transpose")
 
 
 def advance_cursor(cursor: torch.Tensor, n: int):

@@ -132,9 +132,24 @@ class _BaseTrainer:
         self._bind_set(live_set)
         self.engine.reset_step_workspace(live)
 
-    def _run_eager(self, pos: int, n: int):
+    # -- a chunk of steps: trainers that keep state in another form between the ends of a chunk hook in here ----
+    def _chunk_begin(self, n: int):
+        """Called before the first step of a chunk of ``n`` steps (eager, warm-up or under capture)."""
+
+    def _chunk_end(self):
+        """Called after the last step of a chunk."""
+
+    def _steps(self, pos: int, n: int, like: int = None, repeat_first: bool = False):
+        """``n`` steps from epoch position ``pos`` as one chunk.  ``like``: take the form a chunk of that many steps
+        would take (warm-up steps have to launch the kernels of the chunk they precede); ``repeat_first``: every step
+        on batch ``pos``."""
+        self._chunk_begin(n if like is None else like)
         for i in range(n):
-            self._one_step(pos + i)
+            self._one_step(pos if repeat_first else pos + i)
+        self._chunk_end()
+
+    def _run_eager(self, pos: int, n: int):
+        self._steps(pos, n)
         self.engine.advance(n)
 
     def _get_graph(self, pos: int, n: int, parity: int, dset: int = None):
@@ -166,8 +181,7 @@ class _BaseTrainer:
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            for _ in range(3):
-                self._one_step(pos)
+            self._steps(pos, 3, like=n, repeat_first=True)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._restore(snap)
@@ -175,8 +189,7 @@ class _BaseTrainer:
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for i in range(n):
-                self._one_step(pos + i)     # the engine flips its parity per step
+            self._steps(pos, n)             # the engine flips its parity per step
         self.engine.parity = parity         # capture did not execute anything
         return graph
 
@@ -621,16 +634,14 @@ class XgmiTowerTrainer(_BaseTrainer):
         # results are rolled back; two of them, so that the slots keep alternating.
         snap = self._snapshot()
         self.engine.reset_step_workspace(parity)
-        for i in range(2):
-            self._one_step(pos)
+        self._steps(pos, 2, like=n, repeat_first=True)
         torch.cuda.synchronize(self.device)
         self._restore(snap)
         self.engine.reset_step_workspace(parity)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for i in range(n):
-                self._one_step(pos + i)
+            self._steps(pos, n)
         self.engine.parity = parity
         return graph
 
@@ -683,15 +694,45 @@ class XgmiFusedTrainer(_BaseTrainer):
         self._xg_offs = {role: self.layout.var_range[name][0] for role, name in
                          (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
                           ("b2", "biases/Variable_1"))}
-        self._xg_desc = None if local_peers else self.xg.step_descriptor(self._xg_offs)
+        # Between the ends of a chunk W1 lives TRANSPOSED ([H][K]): the forward tiles read 8 contiguous rows of that
+        # image with 16-byte loads instead of 784 pieces of 32 bytes of W1[K][H], the backward updates it in place;
+        # one transposition launch at either end of the chunk (every replica takes the same decision: same chunk
+        # lengths everywhere).  DTF_XG_W1T=0: W1 as it is.
+        self._W1 = self.layout.mlp_views(self.params)["W1"]
+        self.use_w1t = (os.environ.get("DTF_XG_W1T", "1") != "0" and self.engine.K % 4 == 0 and self.engine.K <= 1024
+                        and self._W1.data_ptr() % 16 == 0)
+        self._w1t = torch.empty((self.engine.H, self.engine.K), dtype=torch.float32, device=self.device) \
+            if self.use_w1t else None
+        self._in_w1t = False
+        self._xg_desc = self._xg_desc_t = None
+        if not local_peers:
+            self._make_descriptors()
+
+    W1T_MIN_STEPS = 8      # two transposition launches per chunk: shorter chunks keep W1 as it is
+
+    def _make_descriptors(self):
+        self._xg_desc = self.xg.step_descriptor(self._xg_offs)
+        if self.use_w1t:
+            self._xg_desc_t = self.xg.step_descriptor(self._xg_offs)
+            self._xg_desc_t.w1t = self._w1t.data_ptr()
 
     def connect_local(self, towers):
         """Replicas driven by ONE process (in-graph towers): wire the inboxes with plain pointers."""
         self.xg.connect_local([t.xg for t in towers if t is not self])
-        self._xg_desc = self.xg.step_descriptor(self._xg_offs)
+        self._make_descriptors()
+
+    def _chunk_begin(self, n: int):
+        self._in_w1t = self.use_w1t and n >= self.W1T_MIN_STEPS
+        if self._in_w1t:
+            hb.transpose(self._W1, self._w1t)
+
+    def _chunk_end(self):
+        if self._in_w1t:
+            hb.transpose(self._w1t, self._W1)
+            self._in_w1t = False
 
     def _one_step(self, batch_index: int):
-        self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
+        self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc_t if self._in_w1t else self._xg_desc)
 
     _capture = XgmiTowerTrainer._capture
     replica_checksum = XgmiTowerTrainer.replica_checksum
@@ -731,7 +772,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
     name = "xgmi_async"
 
-    def __init__(self, *a, group=None, fused_push: bool = True, **kw):
+    def __init__(self, *a, group=None, fused_push: bool = True, fold_pull: bool = True, **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("the peer-mapped shards are a GPU path")
@@ -739,6 +780,9 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
         self.group = group
         self.fused_push = bool(fused_push)
+        # fold_pull: no pull launch either -- the forward reads W1 / b1 / W2 / b2 from the shards through the
+        # mappings and snapshots W2 / b2 for the backward (2 launches per step; needs the fused push)
+        self.fold_pull = bool(fold_pull) and self.fused_push and os.environ.get("DTF_ASYNC_FOLD_PULL", "1") != "0"
         chunk = self.layout.shard_numel(0)
         self.shards = PeerShards(self.rank, self.world, chunk, self.device, group=group)
         if self.shards.total != self.params.numel():
@@ -756,17 +800,25 @@ class XgmiAsyncTrainer(_BaseTrainer):
             offs = {role: self.layout.var_range[name][0] for role, name in
                     (("W1", "weights/Variable"), ("b1", "biases/Variable"), ("W2", "weights/Variable_1"),
                      ("b2", "biases/Variable_1"))}
-            self._push_desc = self.shards.step_descriptor(offs, self.step_index)
             # same for the pushing backward: the engine reads lr from its own tensor, so a zero there for one step
-            dry = self.shards.step_descriptor(offs, -1)
             keep = self.engine.lr.clone()
             self.engine.lr.zero_()
-            self.engine.step_async(0, dry)
+            if self.fold_pull:
+                try:
+                    self.engine.step_async(0, self.shards.step_descriptor(offs, -1, read_shards=True))
+                except hb.HipKernelError:       # shards too short for the forward's range lookup: keep the pull launch
+                    self.fold_pull = False
+            self.engine.step_async(0, self.shards.step_descriptor(offs, -1))
             self.engine.lr.copy_(keep)
             torch.cuda.synchronize(self.device)
             self.engine.reset_step_workspace(0)
+            self._push_desc = self.shards.step_descriptor(offs, self.step_index, read_shards=self.fold_pull)
 
     def _one_step(self, batch_index: int):
+        if self.fold_pull:
+            with span("pull_step_push_apply"):
+                self.engine.step_async(batch_index, self._push_desc)
+            return
         with span("pull"):
             self.shards.pull(self.params)
         if self.fused_push:
@@ -784,8 +836,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for i in range(n):
-                self._one_step(pos + i)
+            self._steps(pos, n)
         self.engine.parity = parity
         return graph
 
@@ -797,11 +848,21 @@ class XgmiAsyncTrainer(_BaseTrainer):
         self.shards.pull(self.params)
         return int(round(float(self.global_step.item())))
 
+    def fetch_window_async(self, first_step: int, count: int, want_history: bool = False):
+        if self.fold_pull:          # the private copy (and the step counter in it) is not refreshed by the steps
+            self.shards.pull(self.params)
+        return super().fetch_window_async(first_step, count, want_history)
+
     def close(self):
         self._graphs.clear()
         self.shards.close()
 
     def describe(self):
+        if self.fold_pull:
+            return (f"async PS dp{self.world}: shard per GPU in HBM, forward that reads the variables from the shards -> "
+                    f"backward that pushes -lr*g per element into the owning shard with float atomics (2 launches/step) "
+                    f"through peer mappings, no barrier"
+                    + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
         push = ("forward -> backward that pushes -lr*g per element into the owning shard with float atomics "
                 "(3 launches/step)" if self.fused_push else
                 "2 launches -> one-sided lock-free SGD push (1 launch)")

@@ -387,6 +387,9 @@ class InGraphEngine:
                 tr.engine.reset_step_workspace(parity)
         import os
         debug = os.environ.get("DTF_TOWERS_DEBUG") == "1"
+        for t, tr in enumerate(tw):
+            with self._on(t):
+                tr._chunk_begin(k)                # (the warm-up steps launch the kernels of the chunk captured below)
         for w in range(2):                        # real exchanges among all towers, rolled back below
             before = [tr.xg.exchanges_done() for tr in tw] if debug else None
             for t, tr in enumerate(tw):
@@ -399,6 +402,9 @@ class InGraphEngine:
                 if any(bad) or any(a != b + 1 for a, b in zip(after, before)):
                     print(f"[towers debug] capture ({pos},{k},{parity}) warm-up {w}: exchange numbers {before} -> {after}, "
                           f"failed {bad}, raw state {[tr.xg.state.cpu().tolist() for tr in tw]}", flush=True)
+        for t, tr in enumerate(tw):
+            with self._on(t):
+                tr._chunk_end()
         self.synchronize()
         for t, tr in enumerate(tw):
             with self._on(t):
@@ -409,8 +415,7 @@ class InGraphEngine:
             with torch.cuda.device(self.devices[t]):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self.streams[t], capture_error_mode="thread_local"):
-                    for i in range(k):
-                        tr._one_step(pos + i)
+                    tr._steps(pos, k)
                 tr.engine.parity = parity
                 tr._graphs[(pos, k, parity, tr._bound_set)] = graph
         self._graph_keys.add((pos, k, parity))

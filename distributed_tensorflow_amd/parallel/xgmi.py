@@ -451,9 +451,10 @@ class PeerShards:
                                                  torch.cuda.current_stream(self.device).cuda_stream),
                   "dtf_xgmi_push_sgd")
 
-    def step_descriptor(self, offsets: dict, step_index: int = -1) -> "hb.DtfXgDesc":
+    def step_descriptor(self, offsets: dict, step_index: int = -1, read_shards: bool = False) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_async``: the shard buffers of every rank, the element offsets of W1 / b1 /
-        W2 / b2 inside the sharded slab and the element that counts the pushes (< 0: not counted)."""
+        W2 / b2 inside the sharded slab and the element that counts the pushes (< 0: not counted).  ``read_shards``:
+        the step's forward reads the variables from the shards themselves (no ``pull`` before the step)."""
         d = hb.DtfXgDesc()
         for r in range(self.world):
             d.inbox[r] = self._tab[r]
@@ -462,6 +463,7 @@ class PeerShards:
         d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
         d.rank, d.world, d.timeout_ms = self.rank, self.world, 0
         d.step_index = int(step_index)
+        d.compact = 1 if read_shards else 0
         return d
 
     def close(self):

@@ -87,19 +87,25 @@ def test_one_async_worker_trains_the_same_with_either_push():
     x = torch.rand(800, 784, generator=g)
     y = torch.eye(10)[torch.randint(0, 10, (800,), generator=g)]
     out = {}
-    for fused in (True, False):
+    # "fold": the forward reads the variables from the shards (2 launches); "fused": pull launch + forward + pushing
+    # backward (3); "separate": pull, forward, backward into a gradient slab, push kernel (4)
+    for name, kw in (("fold", dict(fused_push=True, fold_pull=True)), ("fused", dict(fused_push=True, fold_pull=False)),
+                     ("separate", dict(fused_push=False))):
         ds = DeviceDataset(x, y, dev, 100, seed=5)
         t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.05, seed=1, rank=0, world=1,
-                                  chunk=4, use_graph=fused, fused_push=fused)
+                                  chunk=4, use_graph=name != "separate", **kw)
+        assert t.fold_pull == (name == "fold")
+        assert ("2 launches/step" in t.describe()) == (name == "fold")
         p0 = t.params.clone()
         t.prepare((12,))
         t.run_steps(12)
         torch.cuda.synchronize()
         assert t.global_step_value() == 12
-        out[fused] = t.params.clone()
-        assert float((out[fused] - p0)[4:].abs().max()) > 1e-3
+        out[name] = t.params.clone()
+        assert float((out[name] - p0)[4:].abs().max()) > 1e-3
         t.close()
-    assert torch.allclose(out[True], out[False], rtol=0, atol=1e-6), float((out[True] - out[False]).abs().max())
+    for name in ("fold", "fused"):
+        assert torch.allclose(out[name], out["separate"], rtol=0, atol=2e-6), (name, float((out[name] - out["separate"]).abs().max()))
 
 
 @pytest.mark.gpu
