@@ -55,24 +55,56 @@ def _sync(device, distributed: bool):
         torch.cuda.synchronize(device)
 
 
+def _aligned_start(device, distributed: bool, lead_s: float = 0.002) -> None:
+    """The opening bracket of a timed region: barrier + device synchronisation and then, on every rank, a wait for the
+    SAME instant of the node's monotonic clock (rank 0 names it).  Ranks leave a barrier up to milliseconds apart, and
+    replicas that wait for each other inside their kernels would book that skew as step time: with 20 timed steps of
+    10 us it is most of the bracket."""
+    import torch.distributed as dist
+
+    _sync(device, distributed)
+    if not distributed:
+        return
+    t = torch.tensor([time.monotonic() + lead_s], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=0)
+    target = float(t.item())
+    if target - time.monotonic() > 1.0:         # clocks that do not agree (not one node): no common instant
+        return
+    while time.monotonic() < target:
+        pass
+
+
 class Watchdog:
     """Bounds the wall time of the run.  ``hold(result)`` registers what rank 0 prints if the deadline passes
     (or ``emit`` is never reached); without a held result an expiry ends the process with status 3."""
 
     def __init__(self, rank: int, seconds: float):
         self.rank, self.deadline = rank, time.monotonic() + seconds
+        self._t0 = time.monotonic()
         self._lock = threading.Lock()
         self._result = None
         self._emitted = False
         self._stage = "start"
         self._stage_deadline = None
+        self._stage_began = time.monotonic()
+        self.stage_s = {}                   # wall seconds per stage, in the order the stages ran
         t = threading.Thread(target=self._run, daemon=True)
         t.start()
 
     def stage(self, name: str, limit_s: Optional[float] = None):
         """Names what runs now; ``limit_s`` bounds THIS stage (an optional one that may hang in a collective)."""
-        self._stage = name
-        self._stage_deadline = None if limit_s is None else time.monotonic() + limit_s
+        now = time.monotonic()
+        self.stage_s[self._stage] = round(self.stage_s.get(self._stage, 0.0) + now - self._stage_began, 2)
+        if self.rank == 0 and os.environ.get("DTF_BENCH_QUIET") != "1":
+            print(f"[bench] +{now - self._t0:6.1f} s  {name}", file=sys.stderr, flush=True)
+        self._stage, self._stage_began = name, now
+        self._stage_deadline = None if limit_s is None else now + limit_s
+
+    def stages(self) -> dict:
+        """Seconds per stage so far, the running one included."""
+        out = dict(self.stage_s)
+        out[self._stage] = round(out.get(self._stage, 0.0) + time.monotonic() - self._stage_began, 2)
+        return out
 
     def hold(self, result: Optional[dict]):
         with self._lock:
@@ -108,6 +140,7 @@ class Watchdog:
             pass
         if self.rank == 0 and res is not None:
             res["truncated_at_stage"] = self._stage
+            res["stage_s"] = self.stages()
             print(json.dumps(res), flush=True)
         os._exit(0 if res is not None or self.rank != 0 else 3)
 
@@ -166,7 +199,7 @@ def _trial_xgmi(rank: int, local_rank: int, world: int, chunk: int, budget_s: fl
     return res
 
 
-def _child_async_rccl(rank: int, dev_index: int, world: int, steps: int, warmup: int, limit_s: float = 90.0) -> dict:
+def _child_async_rccl(rank: int, dev_index: int, world: int, steps: int, warmup: int, limit_s: float = 60.0) -> dict:
     """The two-sided asynchronous transport over RCCL, measured by a child process per rank that starts its HIP
     runtime with a larger pool of hardware queues (parallel/async_rccl_probe.py says why)."""
     import subprocess
@@ -235,7 +268,7 @@ def _child_dense_dp(rank: int, dev_index: int, world: int, backend: str, limit_s
     return {"error": f"{note}: {text[-300:]}"}
 
 
-def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 150.0) -> dict:
+def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 100.0) -> dict:
     """In-graph replication measured by a client process of its own (``bench.py --mode ingraph``): one engine per
     process is how the engine is used and tested, and a rank that has built half a dozen trainers before is not that;
     whatever happens to the client stays in the client."""
@@ -276,6 +309,59 @@ def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float =
     return {"error": f"{note}: {text[-300:]}"}
 
 
+def _child_per_batch_epoch(use_cpu: bool, limit_s: float = 90.0) -> dict:
+    """The reference's LITERAL epoch (tfsingle.py:72-97): 550 x {next_batch, ``sess.run([train_op, cost, summary,
+    global_step], feed_dict)``, ``add_summary``} + the full test-set evaluation, timed by the script itself as
+    "Total Time".  Runs the repository's ``tfsingle.py`` unmodified in a process of its own for 3 epochs and reports the
+    fastest of the epochs after the first (the first one holds kernel loading and the event file's creation)."""
+    import re
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k)
+    if use_cpu:
+        env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    exact = None
+    with tempfile.TemporaryDirectory() as logs:
+        cmd = [sys.executable, os.path.join(root, "tfsingle.py"), "--epochs", "3", "--logs_path", logs]
+        if use_cpu:
+            cmd += ["--train_size", "5500"]
+        env["DTF_EPOCH_TIMES_FILE"] = os.path.join(logs, "epoch_times.json")     # the same times, not rounded to 10 ms
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=limit_s,
+                               cwd=logs)
+            text = r.stdout
+        except subprocess.TimeoutExpired as e:
+            text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        try:
+            with open(env["DTF_EPOCH_TIMES_FILE"]) as f:
+                exact = [float(v) for v in json.load(f)["epoch_times"]]
+        except (OSError, ValueError, KeyError):
+            exact = None
+    times = [float(v) for v in re.findall(r"Total Time: ([\d.]+)s", text)]
+    steps = [int(v) for v in re.findall(r"Batch:\s*\d+ of\s*(\d+)", text)]
+    accs = re.findall(r"Test-Accuracy: ([\d.]+)", text)
+    if len(times) < 2:
+        return {"error": "tfsingle.py did not finish two epochs: " + text[-300:]}
+    # (the script prints seconds with two decimals; the per-step figure comes from its AvgTime lines)
+    avg = [float(v) for v in re.findall(r"AvgTime:\s*([\d.]+)ms", text)]
+    steady = avg[6:] if len(avg) > 6 else avg
+    printed = min(times[1:])
+    if exact and len(exact) == len(times):
+        times = exact
+    return {"sec_per_epoch": round(min(times[1:]), 5), "sec_per_epoch_as_printed": printed,
+            "first_epoch_s": round(times[0], 4), "epochs_run": len(times),
+            "steps_per_epoch": steps[-1] if steps else None,
+            "ms_per_batch_steady": round(sorted(steady)[len(steady) // 2], 4) if steady else None,
+            "test_accuracy": float(accs[-1]) if accs else None,
+            "what": "tfsingle.py unmodified: one sess.run with feed_dict and four fetches per batch, one event-file "
+                    "record per batch, full test-set evaluation per epoch; the script's own 'Total Time'"}
+
+
 def run_benchmark(args) -> Optional[dict]:
     import torch.distributed as dist
 
@@ -301,7 +387,7 @@ def run_benchmark(args) -> Optional[dict]:
         # a replay is paid 11 times less often); the multi-rank modes keep their graphs short
         args.chunk = STEPS_PER_EPOCH if mode == "single" else 50
     wd = Watchdog(rank, float(os.environ.get("DTF_BENCH_DEADLINE_S", "900")))
-    soft_budget = float(os.environ.get("DTF_BENCH_BUDGET_S", "240"))     # no NEW optional stage after this
+    soft_budget = float(os.environ.get("DTF_BENCH_BUDGET_S", "170"))     # no NEW optional stage after this
     # device_count() does not create a GPU context, so the trial below still runs ahead of ours
     use_cpu = bool(args.cpu) or torch.cuda.device_count() == 0
     # Test hook: every rank on GPU 0 with a gloo rendezvous (RCCL refuses two ranks on one device), so that
@@ -312,7 +398,7 @@ def run_benchmark(args) -> Optional[dict]:
     if mode == "auto" and distributed and not use_cpu and os.environ.get("DTF_BENCH_XGMI", "1") != "0":
         wd.stage("peer-exchange trial (child processes)")
         trial = _trial_xgmi(rank, dev_index, world, int(args.chunk),
-                            budget_s=float(os.environ.get("DTF_BENCH_TRIAL_S", "75")))
+                            budget_s=float(os.environ.get("DTF_BENCH_TRIAL_S", "45")))
     use_cpu = use_cpu or not torch.cuda.is_available()
     if use_cpu:
         device = torch.device("cpu")
@@ -348,7 +434,7 @@ def run_benchmark(args) -> Optional[dict]:
         dist.broadcast(flag, src=0)
         return bool(int(flag.item()))
 
-    trial_ok = {}
+    trial_ok, trial_ms = {}, {}
     if trial is not None:
         keys = ("ok", "async_ok", "ok2", "ok2c", "ok2p")
         flag = torch.tensor([1 if trial.get(k) else 0 for k in keys], dtype=torch.int32, device=device)
@@ -356,6 +442,11 @@ def run_benchmark(args) -> Optional[dict]:
         trial_ok = dict(zip(keys, (bool(int(v)) for v in flag.tolist())))
         if rank == 0 and not all(trial_ok.values()):
             print(f"[bench] peer-mapped trial verdicts {trial_ok}: {trial}", file=sys.stderr, flush=True)
+        # the trial's own timings (maxima over its ranks, made identical here) rank the exchanges that passed
+        tkeys = ("ms_per_step", "ms_per_step2", "ms_per_step2c", "ms_per_step2p")
+        tms = torch.tensor([float(trial.get(k) or 1e9) for k in tkeys], dtype=torch.float64, device=device)
+        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+        trial_ms = dict(zip(("xgmi", "xgmi2", "xgmi2c", "xgmi2p"), (float(v) for v in tms.tolist())))
 
     # ---- resident data: every worker trains on its own independently shuffled copy (tfdist_between.py:92) ------
     wd.stage("data set")
@@ -424,23 +515,35 @@ def run_benchmark(args) -> Optional[dict]:
             return None, None, {"error": err or "failed on another rank"}
         prepare(tr, (w, k) + tuple(extra_hint))
         build_s = time.perf_counter() - t_b
+        dev_ms = 0.0
         try:
             tr.run_steps(w)
-            _sync(device, distributed)
+            _aligned_start(device, distributed)
+            # the K steps on the device's own clock as well: two events inside the bracket (the host number between the
+            # barriers also holds the launch of the first graph from an idle device and the closing barrier)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if device.type == "cuda" else None
+            if ev:
+                ev[0].record()
             t0 = time.perf_counter()
             tr.run_steps(k)
+            if ev:
+                ev[1].record()
             _sync(device, distributed)
             dt = time.perf_counter() - t0
+            if ev:
+                dev_ms = float(ev[0].elapsed_time(ev[1]))
         except Exception as e:  # noqa: BLE001
             err, dt = f"run: {type(e).__name__}: {e}", 0.0
         if not agree(err is None):
             retire(tr)
             return None, None, {"error": err or "failed on another rank"}
         if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # identical decisions on every rank
-            dt = float(t.item())
+            dt, dev_ms = float(t[0].item()), float(t[1].item())
         info = {"build_and_capture_s": round(build_s, 3)}
+        if device.type == "cuda":
+            info["ms_per_step_device"] = round(dev_ms / k, 5)
         if cand in PEER_MODES:
             # The replicas sum in rank order, so they must be bit-identical; anything else (or an exchange that
             # timed out, which skips its work from then on and would look FAST) voids the measurement.
@@ -454,6 +557,7 @@ def run_benchmark(args) -> Optional[dict]:
         return tr, dt, info
 
     # ---- the synchronous (or single-process) headline -----------------------------------------------------------
+    mode_err_pruned = {}
     if mode == "auto":
         # library collectives first: they are the safe baseline and give the run a result early
         if share_gpu:       # (the one-GPU rehearsal keeps its gloo group out of the per-step path when it can)
@@ -462,13 +566,20 @@ def run_benchmark(args) -> Optional[dict]:
             library = ("towers", "sync")
         cands = list(library)
         if not use_cpu:
-            cands += [m for m, k in (("xgmi2p", "ok2p"), ("xgmi2c", "ok2c"), ("xgmi2", "ok2"), ("xgmi", "ok"))
+            # of the peer-mapped exchanges that passed the trial, the fastest ones by the trial's timings (2 by default:
+            # every candidate costs a build, a capture and a measurement on every rank)
+            passed = [m for m, k in (("xgmi2p", "ok2p"), ("xgmi2c", "ok2c"), ("xgmi2", "ok2"), ("xgmi", "ok"))
                       if trial_ok.get(k)]
+            passed.sort(key=lambda m: trial_ms.get(m, 1e9))
+            keep = max(1, int(os.environ.get("DTF_BENCH_PEER_CANDS", "2")))
+            cands += passed[:keep]
+            for m in passed[keep:]:
+                mode_err_pruned[m] = f"not measured: {trial_ms.get(m):.5f} ms/step in the trial, slower than {passed[:keep]}"
     elif ingraph_only:
         cands = []
     else:
         cands = [mode]
-    mode_ms, mode_err = {}, {}
+    mode_ms, mode_err, mode_dev_ms = {}, dict(mode_err_pruned), {}
     best = None                         # (mode, trainer, seconds, info)
     for i, cand in enumerate(cands):
         if best is not None and not within_budget():
@@ -485,6 +596,8 @@ def run_benchmark(args) -> Optional[dict]:
                 print(f"[bench] {cand} cannot be used here: {info['error']}", file=sys.stderr, flush=True)
             continue
         mode_ms[cand] = round(1000.0 * dt / steps, 5)
+        if "ms_per_step_device" in info:
+            mode_dev_ms[cand] = info["ms_per_step_device"]
         gs = tr.global_step_value()
         if best is None or dt < best[2]:
             if best is not None:
@@ -504,6 +617,8 @@ def run_benchmark(args) -> Optional[dict]:
         mode, trainer, elapsed, info = best
         setup["build_and_capture_s"] = info["build_and_capture_s"]
         result_extra["global_step"] = info["global_step"]
+        if "ms_per_step_device" in info:
+            result_extra["ms_per_step_device"] = info["ms_per_step_device"]
         wd.stage("evaluation + like-for-like epoch")
         loss, acc = trainer.evaluate(test_x, test_y)
         last_cost = trainer.last_loss()
@@ -550,6 +665,8 @@ def run_benchmark(args) -> Optional[dict]:
         retire(trainer)
         if len(cands) > 1:
             result_extra["mode_ms_per_step"] = mode_ms
+            if mode_dev_ms:
+                result_extra["mode_ms_per_step_device"] = mode_dev_ms
         if mode_err:
             result_extra["mode_errors"] = mode_err
         if trial is not None:
@@ -597,6 +714,7 @@ def run_benchmark(args) -> Optional[dict]:
                 a_loss, a_acc = tr.evaluate(test_x, test_y)
                 async_reports[cand] = {
                     "value": round(n * BATCH * a_k / dt, 1), "unit": "samples/s", "ms_per_step": round(1000.0 * dt / a_k, 5),
+                    "ms_per_step_device": info.get("ms_per_step_device"),
                     "steps": a_k, "warmup": a_w, "global_step": a_gs, "every_push_counted": a_gs == n * (a_w + a_k),
                     "test_accuracy_after_run": round(a_acc, 4), "test_loss_after_run": round(a_loss, 4),
                     "measured_in": "this process, on the benchmark's data set", "parallelism": tr.describe()}
@@ -627,7 +745,14 @@ def run_benchmark(args) -> Optional[dict]:
                 if ingraph_only:
                     rep = _measure_ingraph(n, share_gpu or torch.cuda.device_count() < n, mnist, min(warmup, bpe), steps,
                                            int(args.chunk), test_x, test_y, use_cpu)
+                elif os.environ.get("DTF_BENCH_INGRAPH_INPROC") == "1":
+                    # in this very process, after everything this rank has built and retired before
+                    rep = _measure_ingraph(n, share_gpu or torch.cuda.device_count() < n, mnist, min(warmup, bpe),
+                                           min(steps, 4 * bpe), int(args.chunk), test_x, test_y, use_cpu)
+                    rep["measured_in"] = "the benchmark's rank 0 process"
                 else:
+                    # (default: a client process of its own -- a fault on a node this code has never run on then
+                    # costs this stage, not the line rank 0 is about to print)
                     rep = _child_ingraph(n, min(steps, 4 * bpe), min(warmup, bpe), int(args.chunk))
             except Exception as e:  # noqa: BLE001
                 rep = {"error": f"{type(e).__name__}: {e}"}
@@ -657,7 +782,7 @@ def run_benchmark(args) -> Optional[dict]:
     if want_dense_dp and within_budget():
         if rank == 0 and best is not None:      # what is printed should this stage hang in a collective
             wd.hold(_result(n, steps, warmup, elapsed, parallelism, mnist.source, use_cpu, device, ranks_seen, result_extra))
-        dp_limit = float(os.environ.get("DTF_BENCH_DENSE_DP_S", "120"))
+        dp_limit = float(os.environ.get("DTF_BENCH_DENSE_DP_S", "75"))
         wd.stage("dense stack, data parallel", limit_s=dp_limit + 30.0)
         try:
             if use_cpu:         # (CPU rehearsal of the flow: in this process, over the gloo group at hand)
@@ -671,6 +796,18 @@ def run_benchmark(args) -> Optional[dict]:
         except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
             rep = {"error": f"{type(e).__name__}: {e}"}
         result_extra["dense_dp"] = rep
+
+    # ---- the reference's literal epoch: its script, one sess.run + one summary record per batch ------------------------
+    if (n == 1 and not ingraph_only and args.mode in (None, "auto", "single")
+            and os.environ.get("DTF_BENCH_PER_BATCH", "1") != "0" and within_budget()):
+        wd.stage("per-batch tier (tfsingle.py, child process)", limit_s=120.0)
+        try:
+            rep = _child_per_batch_epoch(use_cpu)
+        except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
+            rep = {"error": f"{type(e).__name__}: {e}"}
+        result_extra["per_batch_tier"] = rep
+        if "sec_per_epoch" in rep:
+            result_extra["sec_per_epoch_per_batch_tier"] = rep["sec_per_epoch"]
 
     result = None
     if rank == 0:
@@ -686,6 +823,8 @@ def run_benchmark(args) -> Optional[dict]:
             result = _result(n, steps, warmup, elapsed, parallelism, mnist.source, use_cpu, device, ranks_seen, result_extra)
         result["wall_s"] = round(time.monotonic() - t_begin, 1)
     wd.stage("shutdown")
+    if result is not None:
+        result["stage_s"] = dict(wd.stage_s)
     wd.hold(result)
     if distributed:
         try:

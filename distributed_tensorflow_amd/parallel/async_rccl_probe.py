@@ -83,7 +83,8 @@ def main(argv=None) -> int:
                    value=round(args.world * 100 * args.steps / dt, 1), unit="samples/s", global_step=gs,
                    every_push_counted=gs == args.world * (args.steps + args.warmup),
                    test_accuracy_after_run=round(acc, 4), test_loss_after_run=round(loss, 4),
-                   hardware_queues=os.environ["GPU_MAX_HW_QUEUES"], parallelism=tr.describe())
+                   hardware_queues=os.environ["GPU_MAX_HW_QUEUES"], parallelism=tr.describe(),
+                   communicator_setup_s=round(tr.comm_setup_s, 3), library_calls_per_step=tr.host_calls_per_step())
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 — every failure is an answer

@@ -160,6 +160,8 @@ class _BaseTrainer:
             self._bind_set(dset)
             with span("graph_capture", steps=n):
                 g = self._capture(pos, n, parity)
+            if os.environ.get("DTF_GRAPH_UPLOAD", "1") != "0":
+                hb.graph_upload(g)          # the first replay may sit inside somebody's timed region
             self._graphs[key] = g
         return g
 
@@ -467,13 +469,21 @@ class AsyncSendRecvTrainer(_CollectiveTrainer):
         n = self.layout.shard_numel(self.rank)
         self.inbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
         self.outbox = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
-        # pair[(w, k)]: worker w <-> owner k; every rank creates every group, in the same order
+        # pair[(w, k)]: worker w <-> owner k; every rank creates every group, in the same order.  (Creating only the
+        # 2 (N - 1) groups a rank belongs to -- new_group(..., use_local_synchronization=True) -- does not work here:
+        # such groups are named by a hash of their SORTED ranks, so the two communicators a pair needs, one per
+        # direction, get the same name and the second creation hangs; seen with gloo at 4 and 8 ranks.  With RCCL a
+        # group is only a record until its first call, so the N (N - 1) records cost little: comm_setup_s says how much.)
         self.pair = {}
+        import time as _time
+
+        t_comm = _time.perf_counter()
         if self.world > 1:
             for w in range(self.world):
                 for k in range(self.world):
                     if w != k:
                         self.pair[(w, k)] = d.new_group([w, k])
+        self.comm_setup_s = _time.perf_counter() - t_comm
         self._lock = None
         if not self.stream_ordered:
             import threading
@@ -506,8 +516,13 @@ class AsyncSendRecvTrainer(_CollectiveTrainer):
         d, grp = self.dist, self.pair[(w, self.rank)]
         d.recv(self.inbox[w], src=w, group=grp)
         self._apply_to_shard(self.inbox[w])
-        self.outbox[w].copy_(self.shard)          # a snapshot: the shard keeps changing under other lanes
-        d.send(self.outbox[w], dst=w, group=grp)
+        if self.use_locking or not self.stream_ordered:
+            self.outbox[w].copy_(self.shard)      # a snapshot: the shard keeps changing under other lanes
+            d.send(self.outbox[w], dst=w, group=grp)
+        else:
+            # unlocked (the reference's default): the answer is read straight out of the live shard, as an unlocked
+            # read of a variable that other lanes are updating is in the reference -- no staging copy
+            d.send(self.shard, dst=w, group=grp)
 
     def _service_thread(self, w: int, n: int, errors: list):
         try:
@@ -522,6 +537,22 @@ class AsyncSendRecvTrainer(_CollectiveTrainer):
     def _one_step(self, batch_index: int):
         d = self.dist
         self.engine.step_grad(batch_index, scale=1.0)
+        if self.stream_ordered:
+            # per peer ONE coalesced call (ncclGroupStart / End): the push of this worker's gradient range and the
+            # receive of the owner's answer, which the owner sends after it has applied that gradient
+            works = []
+            for k in range(self.world):
+                if k == self.rank:
+                    continue
+                a, b = self.layout.shard_range[k]
+                grp = self.pair[(self.rank, k)]
+                works += d.batch_isend_irecv([d.P2POp(d.isend, self.grads[a:b], k, group=grp),
+                                              d.P2POp(d.irecv, self.params[a:b], k, group=grp)])
+            self._apply_to_shard(self.my_grads)          # own shard: no communicator between a rank and itself
+            self.my_params.copy_(self.shard)
+            for wk in works:
+                wk.wait()                                # (stream-ordered: the host does not block)
+            return
         for k in range(self.world):
             a, b = self.layout.shard_range[k]
             if k == self.rank:
@@ -588,11 +619,18 @@ class AsyncSendRecvTrainer(_CollectiveTrainer):
         self._refresh()
         return int(round(float(self.global_step.item())))
 
+    def host_calls_per_step(self) -> int:
+        """Library calls a rank issues per step: as a worker (one coalesced send + receive per peer with RCCL, two calls
+        per peer otherwise) and as the owner of its shard (a receive and a send per served worker)."""
+        peers = self.world - 1
+        return peers * (1 if self.stream_ordered else 2) + 2 * peers
+
     def describe(self):
         lane = "side HIP stream" if self.stream_ordered else "service thread"
-        return (f"async PS dp{self.world} over {self.backend} send/recv: one communicator and one {lane} per "
-                f"(worker, shard) pair, owner applies with the SGD kernel "
-                f"({'atomic adds' if self.use_locking else 'unlocked whole-vector update'}), eager")
+        return (f"async PS dp{self.world} over {self.backend} send/recv (the two-sided library yardstick of the one-sided "
+                f"shards): one communicator and one {lane} per (worker, shard) pair, owner applies with the SGD kernel "
+                f"({'atomic adds' if self.use_locking else 'unlocked whole-vector update'}), eager, "
+                f"{self.host_calls_per_step()} library calls per rank and step")
 
 
 class XgmiTowerTrainer(_BaseTrainer):

@@ -417,6 +417,8 @@ class InGraphEngine:
                 with torch.cuda.graph(graph, stream=self.streams[t], capture_error_mode="thread_local"):
                     tr._steps(pos, k)
                 tr.engine.parity = parity
+                with torch.cuda.stream(self.streams[t]):
+                    hb.graph_upload(graph)          # not during the first replay, which somebody may be timing
                 tr._graphs[(pos, k, parity, tr._bound_set)] = graph
         self._graph_keys.add((pos, k, parity))
 

@@ -136,7 +136,10 @@ def main(argv=None) -> int:
         # requests) and with the push as a launch of its own (whole vectors); the faster form that kept every push
         # is the one reported
         forms = {}
-        for fused_push in (True, False):
+        import os
+
+        # (the push as a launch of its own is the older form: tried only on request, it costs the trial a stage)
+        for fused_push in ((True, False) if os.environ.get("DTF_TRIAL_ASYNC_BOTH") == "1" else (True,)):
             if not go_on("async, push " + ("in the backward" if fused_push else "as a launch")):
                 continue
             ta = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=100, lr=0.001, seed=1,
