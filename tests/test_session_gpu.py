@@ -136,7 +136,8 @@ def test_resident_async_workers_replay_hipgraphs_against_ipc_shards(n_ps, n_w, t
     # worker prints the value its last WINDOW pulled: workers whose last windows run side by side (they usually do not:
     # one of them tends to finish first and the other then prints 88) each miss the other's updates still in flight.
     # Observed when they do overlap: 86 and 85 of 88.
-    assert 2 * 22 * n_w - 3 * (n_w - 1) <= max(finals) <= 2 * 22 * n_w
+    # (bound: every other worker may still have a whole window of 11 updates in flight when the last window pulls)
+    assert 2 * 22 * n_w - 11 * (n_w - 1) <= max(finals) <= 2 * 22 * n_w
     assert all(c[-1] < c[0] for c in costs)                 # the shared model learns
 
 
@@ -160,7 +161,7 @@ def test_resident_async_workers_of_a_deeper_stack_replay_hipgraphs_against_ipc_s
         assert out.rstrip().endswith("Done")
         finals.append([int(s) for s in re.findall(r"Step: (\d+),", out)][-1])
         costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
-    assert 2 * 22 * n_w - 3 * (n_w - 1) <= max(finals) <= 2 * 22 * n_w       # every push is an update (see above)
+    assert 2 * 22 * n_w - 11 * (n_w - 1) <= max(finals) <= 2 * 22 * n_w       # every push is an update (see above)
     assert all(c[-1] < c[0] for c in costs)
 
 
