@@ -109,6 +109,7 @@ SANITIZERS = {
 STRESS_SOURCES = {
     "server_stress": ["stress/server_stress.cpp", "ps_server.cpp"],
     "records_stress": ["stress/records_stress.cpp", "records.cpp"],
+    "board_stress": ["stress/board_stress.cpp", "shm_board.cpp"],
 }
 
 

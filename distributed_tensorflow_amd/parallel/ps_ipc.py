@@ -50,6 +50,7 @@ from typing import List, Optional
 import torch
 
 from ..ops import hip_backend as hb
+from ..runtime import native as rt
 from ..utils.trace import span
 from ..variables import ShardLayout
 from .store import FINISHED_KEY, INIT_KEY, TOKEN_Q, spread_tokens, token_key
@@ -57,6 +58,7 @@ from .store import FINISHED_KEY, INIT_KEY, TOKEN_Q, spread_tokens, token_key
 ALLOC_KEY = "__ipc_alloc__"
 HANDLE_KEY = "__ipc_handle__"
 ARRIVAL_Q = "__ipc_arrival_q__"
+BOARD_KEY = "__ipc_barrier_board__"       # name of the shared-memory board of the barrier (empty: use the sockets)
 ACC_STEP = "__ipc_acc_step__"
 LOCK_Q = "__ipc_lock__"
 
@@ -161,6 +163,40 @@ class IpcVariableStore:
     def _c(self, k: int):
         return self.server.client("ps", k)
 
+    # -- the barrier's control plane: shared memory when every task runs on this node, the task server otherwise ----
+    def _all_tasks_local(self) -> bool:
+        import socket
+
+        here = {"localhost", "127.0.0.1", "::1", "0.0.0.0", socket.gethostname()}
+        spec = self.server.cluster
+        return all(addr.rsplit(":", 1)[0] in here for job in spec.jobs for addr in spec.job_tasks(job))
+
+    def _create_board(self):
+        """Chief, when the variables are initialised: create the board and publish its name (an empty name tells the
+        other tasks to stay on the sockets: tasks on several hosts, or DTF_SYNC_BOARD=0)."""
+        import os
+
+        if getattr(self, "_board_known", False):        # (a restore after the initialisation: same board)
+            self._c(self._gs_shard).set(BOARD_KEY, self._board.name.encode() if self._board is not None else b"")
+            return
+        self._board, name = None, b""
+        if os.environ.get("DTF_SYNC_BOARD", "1") != "0" and self._all_tasks_local():
+            try:
+                port = self.server.cluster.task_address("ps", self._gs_shard).rsplit(":", 1)[1]
+                self._board = rt.Board(rt.Board.unique_name(port), self.n_workers, create=True)
+                name = self._board.name.encode()
+            except Exception as e:  # noqa: BLE001 — no shared memory here: the sockets still work
+                print(f"[ipc store] barrier board unavailable ({e}); using the task server", flush=True)
+        self._board_known = True
+        self._c(self._gs_shard).set(BOARD_KEY, name)
+
+    def _get_board(self):
+        if not getattr(self, "_board_known", False):
+            name = bytes(self._c(self._gs_shard).get(BOARD_KEY, timeout=self.timeout))
+            self._board = rt.Board(name.decode(), self.n_workers, create=False) if name else None
+            self._board_known = True
+        return self._board
+
     def _lr(self, lr: float) -> torch.Tensor:
         if self._lr_val != lr:
             self._lr_t.fill_(float(lr))
@@ -211,6 +247,7 @@ class IpcVariableStore:
             if self.layout.shard_numel(k):
                 self.layout.initialize(self._params(k), seed, shard=k, slab_offset=self.layout.shard_range[k][0])
         torch.cuda.synchronize(self.device)
+        self._create_board()
         self._c(0).set(INIT_KEY, b"1")
 
     def publish(self, local: torch.Tensor):
@@ -228,6 +265,7 @@ class IpcVariableStore:
             if b > a:
                 self._params(k).copy_(local[a:b])
         torch.cuda.synchronize(self.device)
+        self._create_board()
         self._c(0).set(INIT_KEY, b"1")
 
     # -- data plane --------------------------------------------------------------------------
@@ -309,8 +347,29 @@ class IpcVariableStore:
         return struct.pack("<qqq", self.widx, self.local_step, slot)
 
     def push_accumulate(self, grads: torch.Tensor) -> bool:
-        self._c(self._gs_shard).qpush(ARRIVAL_Q, self._deposit(grads))
+        rec = self._deposit(grads)
+        board = self._get_board()
+        if board is not None:
+            board.arrive(*struct.unpack("<qqq", rec))
+        else:
+            self._c(self._gs_shard).qpush(ARRIVAL_Q, rec)
         return True
+
+    def _announce_and_wait(self, rec: bytes) -> int:
+        """Announce the deposited gradient and wait for this worker's token: through the shared-memory board (no
+        system call unless somebody sleeps), or as one request to the task server."""
+        board = self._get_board()
+        try:
+            if board is not None:
+                board.arrive(*struct.unpack("<qqq", rec))
+                with span("token_wait"):
+                    self.local_step = board.wait_token(self.widx, self.timeout)
+            else:
+                tok = self._c(self._gs_shard).qpush_pop(ARRIVAL_Q, rec, token_key(self.widx), timeout=self.timeout)
+                self.local_step = struct.unpack("<q", tok)[0]
+        except TimeoutError:
+            raise self._no_token() from None
+        return self.local_step
 
     # The gradient can be produced IN the mailbox: the backward kernel's output pointers are views of this worker's
     # mailbox rows (one per variable, in the shard that owns the variable), so a synchronous push moves no bytes.
@@ -336,13 +395,7 @@ class IpcVariableStore:
         synchronised since: announce it and wait for the token (one request)."""
         slot = self._pushes & 1
         self._pushes += 1
-        rec = struct.pack("<qqq", self.widx, self.local_step, slot)
-        try:
-            tok = self._c(self._gs_shard).qpush_pop(ARRIVAL_Q, rec, token_key(self.widx), timeout=self.timeout)
-        except TimeoutError:
-            raise self._no_token() from None
-        self.local_step = struct.unpack("<q", tok)[0]
-        return self.local_step
+        return self._announce_and_wait(struct.pack("<qqq", self.widx, self.local_step, slot))
 
     def _no_token(self):
         return TimeoutError(
@@ -350,22 +403,20 @@ class IpcVariableStore:
             f"is gone (replicas_to_aggregate == total_num_replicas leaves no spare)")
 
     def dequeue_token(self) -> int:
+        board = self._get_board()
         try:
-            tok = self._c(self._gs_shard).qpop(token_key(self.widx), timeout=self.timeout)
+            if board is not None:
+                self.local_step = board.wait_token(self.widx, self.timeout)
+            else:
+                tok = self._c(self._gs_shard).qpop(token_key(self.widx), timeout=self.timeout)
+                self.local_step = struct.unpack("<q", tok)[0]
         except TimeoutError:
             raise self._no_token() from None
-        self.local_step = struct.unpack("<q", tok)[0]
         return self.local_step
 
     def push_accumulate_and_wait(self, grads: torch.Tensor) -> int:
-        """``push_accumulate`` + ``dequeue_token`` as ONE request to the control plane."""
-        rec = self._deposit(grads)
-        try:
-            tok = self._c(self._gs_shard).qpush_pop(ARRIVAL_Q, rec, token_key(self.widx), timeout=self.timeout)
-        except TimeoutError:
-            raise self._no_token() from None
-        self.local_step = struct.unpack("<q", tok)[0]
-        return self.local_step
+        """``push_accumulate`` + ``dequeue_token`` as ONE hand-off to the control plane."""
+        return self._announce_and_wait(self._deposit(grads))
 
     def aggregator_clients(self):
         return [self.server.new_client("ps", k) for k in range(self.n)]
@@ -391,10 +442,14 @@ class IpcVariableStore:
         while len(self._arrived) < num_required:
             # the arrivals still missing, in one request (TimeoutError when none came)
             with span("wait_arrivals"):
-                got, recs = ctl.qpop_n(ARRIVAL_Q, num_required - len(self._arrived),
-                                       timeout=max(0.0, deadline - time.time()))
-            for i in range(got):
-                w, step, slot = struct.unpack_from("<qqq", recs, 24 * i)
+                board = self._get_board()
+                if board is not None:
+                    arrivals = board.take(num_required - len(self._arrived), max(0.0, deadline - time.time()))
+                else:
+                    got, recs = ctl.qpop_n(ARRIVAL_Q, num_required - len(self._arrived),
+                                           timeout=max(0.0, deadline - time.time()))
+                    arrivals = [struct.unpack_from("<qqq", recs, 24 * i) for i in range(got)]
+            for w, step, slot in arrivals:
                 if step < self._acc_step:
                     self.dropped += 1              # stale: its round was applied without it
                 elif all(w != a for a, _ in self._arrived):
@@ -453,8 +508,16 @@ class IpcVariableStore:
         return step
 
     def enqueue_tokens(self, clients, step: int, n: int):
-        tok = struct.pack("<q", int(step))
         per_worker = spread_tokens(n, self.n_workers)
+        board = self._get_board()
+        if board is not None:
+            if per_worker[0] > 0 and len(set(per_worker)) == 1:
+                board.release(-1, int(step), per_worker[0])
+            else:
+                for w, copies in enumerate(per_worker):
+                    board.release(w, int(step), copies)
+            return
+        tok = struct.pack("<q", int(step))
         if per_worker[0] > 0 and len(set(per_worker)) == 1:
             # the usual round (replicas_to_aggregate == number of workers): one request feeds every worker's queue
             clients[self._gs_shard].qpush_fanout(TOKEN_Q, tok, self.n_workers, copies=per_worker[0])

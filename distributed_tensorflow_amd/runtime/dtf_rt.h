@@ -86,6 +86,17 @@ void* dtf_bundle_begin(const char* prefix);
 int dtf_bundle_add_f32(void* bundle, const char* name, const float* data, const int64_t* shape, int ndim);
 int dtf_bundle_finish(void* bundle);   // writes both files atomically (tmp + rename); frees the handle
 
+// --- same-node control plane of the synchronous barrier (shm_board.cpp): arrival queue + per-worker token queues in
+// POSIX shared memory, futexes instead of sockets -------------------------------------------------------------------
+void* dtf_board_open(const char* name, int workers, int create);     // name: "/dtf_board_..."; null on failure
+void dtf_board_close(void* board);
+int dtf_board_unlink(void* board);
+int dtf_board_arrive(void* board, int64_t worker, int64_t step, int64_t slot);
+int dtf_board_take(void* board, int want, int timeout_ms, int64_t* out, int* got);    // out: 3 x int64 per arrival
+int dtf_board_release(void* board, int64_t worker, int64_t step, int copies);         // worker < 0: every worker
+int dtf_board_wait_token(void* board, int64_t worker, int timeout_ms, int64_t* step);
+int dtf_board_attached(void* board);
+
 #ifdef __cplusplus
 }
 #endif

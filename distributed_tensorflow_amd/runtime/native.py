@@ -79,6 +79,16 @@ def lib() -> C.CDLL:
         L.dtf_bundle_begin.argtypes = [C.c_char_p]
         L.dtf_bundle_add_f32.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32]
         L.dtf_bundle_finish.argtypes = [vp]
+        L.dtf_board_open.restype = vp
+        L.dtf_board_open.argtypes = [C.c_char_p, i32, i32]
+        L.dtf_board_close.argtypes = [vp]
+        L.dtf_board_close.restype = None
+        L.dtf_board_unlink.argtypes = [vp]
+        L.dtf_board_arrive.argtypes = [vp, i64, i64, i64]
+        L.dtf_board_take.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i32)]
+        L.dtf_board_release.argtypes = [vp, i64, i64, i32]
+        L.dtf_board_wait_token.argtypes = [vp, i64, i32, C.POINTER(i64)]
+        L.dtf_board_attached.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -371,3 +381,65 @@ def write_bundle(prefix: str, tensors: List[Tuple[str, np.ndarray]]):
             raise OSError("bundle add failed")
     if lib().dtf_bundle_finish(h) != OK:
         raise OSError(f"cannot write checkpoint {prefix}")
+
+
+class Board:
+    """The synchronous barrier's control plane for tasks that share a node (``shm_board.cpp``): an arrival queue and a
+    token queue per worker in POSIX shared memory, waited on with futexes.  The chief creates it under a unique name
+    and publishes the name; every other task opens it.  Thread-safe."""
+
+    def __init__(self, name: str, workers: int, create: bool):
+        self.name, self.workers = name, int(workers)
+        self._h = lib().dtf_board_open(name.encode(), int(workers), 1 if create else 0)
+        if not self._h:
+            raise RuntimeError_(f"cannot {'create' if create else 'open'} the barrier board {name!r} for {workers} workers")
+
+    @staticmethod
+    def unique_name(tag: str) -> str:
+        import os
+        import time as _time
+
+        return f"/dtf_board_{tag}_{os.getpid()}_{int(_time.time() * 1e6) & 0xFFFFFFFF:x}"
+
+    def arrive(self, worker: int, step: int, slot: int):
+        if lib().dtf_board_arrive(self._h, int(worker), int(step), int(slot)) != 0:
+            raise RuntimeError_("barrier board: the arrival queue is full (the aggregator is gone)")
+
+    def take(self, want: int, timeout: float):
+        """Up to ``want`` arrivals as (worker, step, slot) tuples; waits ``timeout`` s for the first (TimeoutError)."""
+        buf = (C.c_int64 * (3 * int(want)))()
+        got = C.c_int(0)
+        rc = lib().dtf_board_take(self._h, int(want), max(0, int(timeout * 1000)), buf, C.byref(got))
+        if rc == 1:
+            raise StoreTimeout("no arrival")
+        if rc != 0:
+            raise RuntimeError_(f"barrier board: take failed ({rc})")
+        return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(got.value)]
+
+    def release(self, worker: int, step: int, copies: int = 1):
+        """``copies`` tokens carrying ``step`` for ``worker`` (-1: for every worker)."""
+        if copies > 0 and lib().dtf_board_release(self._h, int(worker), int(step), int(copies)) != 0:
+            raise RuntimeError_("barrier board: a token queue is full (a replica is gone)")
+
+    def wait_token(self, worker: int, timeout: float) -> int:
+        step = C.c_int64(0)
+        rc = lib().dtf_board_wait_token(self._h, int(worker), max(0, int(timeout * 1000)), C.byref(step))
+        if rc == 1:
+            raise StoreTimeout("no token")
+        if rc != 0:
+            raise RuntimeError_(f"barrier board: wait failed ({rc})")
+        return int(step.value)
+
+    def attached(self) -> int:
+        return int(lib().dtf_board_attached(self._h))
+
+    def close(self):
+        if self._h:
+            lib().dtf_board_close(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -205,3 +205,49 @@ def test_chief_round_in_one_request_and_push_that_waits_for_its_token(server):
     chief.qpush("tok/0", struct.pack("<q", 9))
     ok, tok = workers[0].acc_apply_then_pop("acc", np.zeros(5, dtype=np.float32), 2, "tok/0", timeout=5)
     assert ok is False and struct.unpack("<q", tok)[0] == 9
+
+
+def test_barrier_board_in_shared_memory_passes_arrivals_and_tokens_between_mappings():
+    """runtime/shm_board.cpp through its binding: the chief's mapping and a second mapping of the same board."""
+    import threading
+
+    from distributed_tensorflow_amd.runtime import native as rt
+
+    name = rt.Board.unique_name("test")
+    chief = rt.Board(name, 3, create=True)
+    with pytest.raises(RuntimeError):
+        rt.Board(name, 3, create=True)                  # exclusive create
+    with pytest.raises(RuntimeError):
+        rt.Board(name, 4, create=False)                 # the worker count is part of the contract
+    other = rt.Board(name, 3, create=False)
+    assert chief.attached() == 2
+    with pytest.raises(TimeoutError):
+        chief.take(3, 0.01)
+    with pytest.raises(TimeoutError):
+        other.wait_token(1, 0.01)
+    got = {}
+
+    def replica(w):
+        b = other if w else chief
+        b.arrive(w, 0, w & 1)
+        got[w] = b.wait_token(w, 10.0)
+
+    threads = [threading.Thread(target=replica, args=(w,)) for w in range(3)]
+    for t in threads:
+        t.start()
+    arrivals = []
+    while len(arrivals) < 3:
+        arrivals += chief.take(3 - len(arrivals), 10.0)
+    assert sorted(arrivals) == [(0, 0, 0), (1, 0, 1), (2, 0, 0)]
+    chief.release(-1, 1, 1)                             # one token each, carrying the new step
+    for t in threads:
+        t.join(10)
+    assert got == {0: 1, 1: 1, 2: 1}
+    chief.release(2, 7, 2)                              # two tokens for one worker only
+    assert other.wait_token(2, 1.0) == 7 and other.wait_token(2, 1.0) == 7
+    with pytest.raises(TimeoutError):
+        other.wait_token(0, 0.01)
+    other.close()
+    chief.close()                                       # the creator removes the name
+    with pytest.raises(RuntimeError):
+        rt.Board(name, 3, create=False)

@@ -47,3 +47,12 @@ def test_record_writers_are_clean_under_sanitizers(tmp_path, sanitizer):
     _run([exe, logdir, 4, 200])
     assert len(list(logdir.glob("events.out.tfevents.*"))) == 4
     assert len(list(logdir.glob("model.ckpt-*.index"))) == 4
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_shared_memory_barrier_board_is_clean_under_sanitizers(tmp_path, sanitizer):
+    """The same-node control plane of the synchronous barrier (runtime/shm_board.cpp): replica threads and an
+    aggregator thread in lock step through two mappings of one board."""
+    exe = _build("board_stress", sanitizer, tmp_path)
+    out = _run([exe, 5, 300])
+    assert "workers=5 rounds=300 bad=0" in out
