@@ -259,6 +259,220 @@ class DenseInGraphTowers:
         return all(torch.equal(ref0, p.cpu()) for p in self.params[1:])
 
 
+class DenseInGraphEngine:
+    """In-graph replication of a fully connected stack of any depth as an ENGINE (``tfdist.py --hidden 512,256`` on
+    GPUs): every tower has its own device, HIP stream, replica of the variables in one flat slab, shuffled resident data
+    set and hipGraph chunks of
+
+        the stack's gradient launches (scaled by 1 / N, into one of two gradient slabs that alternate per step)
+        ONE exchange kernel: waits for every tower's slab of this step, sums the N slabs in tower order straight out
+        of the peers' memory (peer access between the GPUs of one process: plain pointers) and applies SGD
+
+    so the client issues one graph launch per tower per chunk and synchronises only when it reads a cost; the replicas
+    stay bit-identical and ``global_step`` advances once per step.  Replaces the host loop of
+    :class:`DenseInGraphTowers` (kept for CPU towers).  Towers may share a GPU (tests, one-GPU rehearsal): their
+    exchange kernels then have to be resident together (a bounded grid of 256 workgroups each)."""
+
+    def __init__(self, devices: Sequence, images, labels, batch: int, lr: float, hidden: Sequence[int], act: str = "relu",
+                 seed: int = 1, chunk: int = 50, data_seed: int = 0, timeout_ms: int = 20000, use_graph: bool = True):
+        from ..models.dense import DenseStackEngine
+        from .xgmi import XgmiExchange
+
+        self.devices = [torch.device(d) for d in devices]
+        if any(d.type != "cuda" for d in self.devices):
+            raise RuntimeError("the exchange kernel is a GPU path (CPU towers: DenseInGraphTowers)")
+        self.n = len(self.devices)
+        self.chunk = max(1, int(chunk))
+        self.use_graph = bool(use_graph)
+        self._closed = False
+        dims = [int(images.shape[1])] + [int(h) for h in hidden] + [int(labels.shape[1])]
+        L = len(dims) - 1
+        pad4 = lambda k: (k + 3) // 4 * 4  # noqa: E731
+        ranges, off = [], 4                      # the first 16 bytes hold the step counter
+        for i in range(L):
+            w = (off, off + dims[i] * dims[i + 1])
+            off = pad4(w[1])
+            b = (off, off + dims[i + 1])
+            off = pad4(b[1])
+            ranges.append((w, b))
+        gen = torch.Generator().manual_seed(int(seed))
+        first = torch.zeros(off, dtype=torch.float32)
+        for i, (w, _) in enumerate(ranges):      # stddev 1 / sqrt(fan-in), biases zero (examples.mnist_mlp._build_deep_model)
+            first[w[0]:w[1]] = (torch.randn(dims[i], dims[i + 1], generator=gen) * dims[i] ** -0.5).reshape(-1)
+        views = lambda slab: [(slab[w[0]:w[1]].view(dims[i], dims[i + 1]), slab[b[0]:b[1]])  # noqa: E731
+                              for i, (w, b) in enumerate(ranges)]
+        distinct = sorted({d.index for d in self.devices})
+        for a in distinct:                      # the exchange kernel of every tower reads every other tower's slabs
+            for b in distinct:
+                hb.enable_peer_access(torch.device("cuda", a), torch.device("cuda", b))
+        self.streams, self._spare_streams = [], []
+        self.params, self.engines, self.datasets, self.xgs, self._gsets, self.steps = [], [], [], [], [], []
+        for t, dev in enumerate(self.devices):
+            with torch.cuda.device(dev):
+                st = InGraphEngine._stream_for_tower(self, dev)
+                with torch.cuda.stream(st):
+                    p = first.clone().to(dev)
+                    xg = XgmiExchange(t, self.n, off, dev, uncached_grads=False, timeout_ms=timeout_ms, connect=False)
+                    for g in xg.grads:                  # whatever no variable covers (step counter, padding) adds zero
+                        g.zero_()
+                    gsets = [views(g) for g in xg.grads]
+                    pv = views(p)
+                    eng = DenseStackEngine([w for w, _ in pv], [b for _, b in pv], [act] * (L - 1), batch=int(batch), lr=lr,
+                                           grads=gsets[0])
+                    ds = DeviceDataset(images, labels, dev, batch, seed=data_seed + t)   # a different shuffle per tower
+                    eng.bind_data(ds.x_epoch, ds.y_epoch)
+                    eng.step_grad(0, 0.0)               # loads the kernels outside any capture (gradients of zero weight)
+                    for g in xg.grads:
+                        g.zero_()
+                st.synchronize()
+            self.streams.append(st)
+            self.params.append(p)
+            self.engines.append(eng)
+            self.datasets.append(ds)
+            self.xgs.append(xg)
+            self._gsets.append(gsets)
+        for xg in self.xgs:
+            xg.connect_local(self.xgs)
+        self.lr = float(lr)
+        self.batches_per_epoch = self.engines[0].batches_per_epoch
+        self._graphs = [dict() for _ in range(self.n)]
+        self._graph_keys = set()
+        # Two real exchanges among all towers with a learning rate of zero (slot 0, then slot 1: the slots keep
+        # alternating into step 0): the exchange kernel is loaded, and has met its peers, before any capture.
+        zero_lr = [torch.zeros(1, dtype=torch.float32, device=d) for d in self.devices]
+        for slot in (0, 1):
+            for t in range(self.n):
+                with self._on(t):
+                    self.xgs[t].apply(self.params[t], zero_lr[t], slot, None)
+        self.synchronize()
+        if not self.healthy():
+            raise RuntimeError("the towers' exchange kernels did not meet (are they resident together?)")
+
+    _on = None          # (set below: the helpers of InGraphEngine that only use .devices / .streams)
+
+    def describe(self) -> str:
+        where = "one GPU each" if len({d.index for d in self.devices}) == self.n else "sharing a GPU"
+        return (f"in-graph: 1 client, {self.n} towers of a dense stack " + "-".join(str(d) for d in self.engines[0].dims)
+                + f" ({where}), a stream and hipGraph chunks of {self.chunk} steps per tower, {self.engines[0].launches_per_step} gradient "
+                f"launches + one exchange kernel per step (sum of the towers' slabs in tower order through peer access, SGD), "
+                f"1 host call per tower per chunk")
+
+    def host_calls_per_chunk(self) -> int:
+        return 1 if self.use_graph else (self.engines[0].launches_per_step + 1) * self.chunk
+
+    def _one_step(self, t: int, bi: int, slot: int):
+        eng = self.engines[t]
+        eng.bind_grads(self._gsets[t][slot])
+        eng.step_grad(bi, 1.0 / self.n)
+        self.xgs[t].apply(self.params[t], eng.lr, slot, self.params[t][0:1])
+
+    def _schedule(self, cursor: int, n: int):
+        bpe, out = self.batches_per_epoch, []
+        while n > 0:
+            k = min(n, self.chunk, bpe - cursor % bpe)
+            out.append(k)
+            cursor += k
+            n -= k
+        return out
+
+    def _capture_all(self, pos: int, k: int, parity: int):
+        InGraphEngine._check_streams(self)
+        self.synchronize()
+        for t in range(self.n):
+            with torch.cuda.device(self.devices[t]):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self.streams[t], capture_error_mode="thread_local"):
+                    for i in range(k):
+                        self._one_step(t, pos + i, (parity + i) & 1)
+                with torch.cuda.stream(self.streams[t]):
+                    hb.graph_upload(graph)
+                self._graphs[t][(pos, k, parity)] = graph
+        self._graph_keys.add((pos, k, parity))
+
+    def prepare(self, steps_hint=()):
+        if not self.use_graph:
+            return
+        cursor = self.engines[0]._host_cursor
+        for n in steps_hint:
+            for k in self._schedule(cursor, n):
+                key = (cursor % self.batches_per_epoch, k, cursor & 1)
+                if key not in self._graph_keys:
+                    self._capture_all(*key)
+                cursor += k
+
+    def run_steps(self, n: int):
+        bpe = self.batches_per_epoch
+        for k in self._schedule(self.engines[0]._host_cursor, n):
+            cur = self.engines[0]._host_cursor
+            pos, parity = cur % bpe, cur & 1
+            if pos == 0 and cur > 0:
+                for t in range(self.n):
+                    with self._on(t):
+                        self.datasets[t].shuffle_epoch()          # in place: captured graphs stay valid
+            if self.use_graph and (pos, k, parity) not in self._graph_keys:
+                self._capture_all(pos, k, parity)
+            for t in range(self.n):
+                with self._on(t):
+                    if self.use_graph:
+                        self._graphs[t][(pos, k, parity)].replay()
+                    else:
+                        for i in range(k):
+                            self._one_step(t, pos + i, (parity + i) & 1)
+                    self.datasets[t].stage_ahead()
+            for eng in self.engines:
+                eng.advance(k)
+
+    # -- the trainer surface shared with the other tower classes (used by the example loop) ----------
+    @property
+    def device(self):
+        return self.devices[0]
+
+    @property
+    def engine(self):
+        return self.engines[0]
+
+    def last_loss(self) -> float:
+        self.synchronize()
+        return sum(e.last_loss() for e in self.engines) / self.n
+
+    def evaluate(self, x, y):
+        self.synchronize()
+        with torch.cuda.device(self.devices[0]):
+            return self.engines[0].evaluate(x, y)
+
+    def global_step_value(self) -> int:
+        self.synchronize()
+        return int(round(float(self.params[0][0].item())))
+
+    def replicas_identical(self) -> bool:
+        self.synchronize()
+        ref0 = self.params[0].cpu()
+        return all(torch.equal(ref0, p.cpu()) for p in self.params[1:])
+
+    def healthy(self) -> bool:
+        self.synchronize()
+        return not any(xg.failed() for xg in self.xgs)
+
+    def diagnostics(self) -> dict:
+        self.synchronize()
+        return {"streams": [hex(s.cuda_stream) for s in self.streams], "exchanges": [xg.exchanges_done() for xg in self.xgs],
+                "failed": [xg.failed() for xg in self.xgs]}
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        try:
+            self.synchronize()
+        except Exception:  # noqa: BLE001 — tearing down after a device error
+            pass
+        for g in self._graphs:
+            g.clear()
+        for t, xg in enumerate(self.xgs):
+            with torch.cuda.device(self.devices[t]):
+                xg.close()
+
+
 class InGraphEngine:
     """One client, N towers, O(1) host calls per tower per chunk (see the module docstring).
 
@@ -518,3 +732,8 @@ class _null:
 
     def __exit__(self, *a):
         return False
+
+
+# helpers of InGraphEngine that only use .devices / .streams serve the dense engine as well
+DenseInGraphEngine._on = InGraphEngine._on
+DenseInGraphEngine.synchronize = InGraphEngine.synchronize

@@ -225,3 +225,41 @@ def test_stack_without_biases_and_with_tall_batch():
                 W = [w.float() for w in Wd]
             for w, we in zip(W, eng.W):
                 torch.testing.assert_close(we.cpu(), w, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.timeout(300)
+def test_in_graph_engine_of_a_dense_stack_one_graph_launch_per_tower_and_chunk():
+    """``DenseInGraphEngine``: two towers sharing the GPU, a stream and hipGraph chunks per tower, the stack's gradient
+    launches and ONE exchange kernel per step.  One step equals the fp64 oracle's step on the mean gradient of both
+    towers' batches; the replicas stay bit-identical across a reshuffle; graph replay equals eager launches."""
+    from distributed_tensorflow_amd.parallel.towers import DenseInGraphEngine
+
+    rng = np.random.RandomState(0)
+    labels = rng.randint(0, 10, 400)
+    images = (rng.rand(10, 784).astype(np.float32)[labels] + 0.3 * rng.rand(400, 784)).astype(np.float32)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    finals = {}
+    for use_graph in (True, False):
+        tw = DenseInGraphEngine(["cuda:0", "cuda:0"], images, onehot, batch=100, lr=0.05, hidden=(32, 16), act="tanh",
+                                seed=1, chunk=3, use_graph=use_graph, timeout_ms=5000)
+        try:
+            assert "784-32-16-10" in tw.describe() and tw.batches_per_epoch == 4
+            assert tw.host_calls_per_chunk() == (1 if use_graph else 3 * (tw.engines[0].launches_per_step + 1))
+            Ws = [w.detach().cpu().clone() for w in tw.engines[0].W]
+            bs = [b.detach().cpu().clone() for b in tw.engines[0].b]
+            x = torch.cat([ds.x_epoch[:100].cpu() for ds in tw.datasets])
+            y = torch.cat([ds.y_epoch[:100].cpu() for ds in tw.datasets])
+            tw.prepare((1, 5))
+            tw.run_steps(1)
+            assert tw.healthy() and tw.replicas_identical() and tw.global_step_value() == 1
+            _oracle_step(Ws, bs, ("tanh", "tanh"), x, y, 0.05)      # the mean over both towers' batches
+            for got, want in zip(tw.engines[1].W + tw.engines[1].b, Ws + bs):
+                torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-6)
+            tw.run_steps(5)                       # crosses the 4-batch epoch boundary (every tower reshuffles its set)
+            assert tw.healthy() and tw.replicas_identical() and tw.global_step_value() == 6
+            loss, acc = tw.evaluate(torch.as_tensor(images).cuda(), torch.as_tensor(onehot).cuda())
+            assert np.isfinite(loss) and 0.0 <= acc <= 1.0
+            finals[use_graph] = tw.params[0].cpu().clone()
+        finally:
+            tw.close()
+    torch.testing.assert_close(finals[True], finals[False], rtol=1e-5, atol=1e-6)

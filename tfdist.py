@@ -28,7 +28,7 @@ FLAGS = tf.app.flags.FLAGS
 def main(_):
     import torch
 
-    from distributed_tensorflow_amd.parallel.towers import DenseInGraphTowers, InGraphEngine, InGraphTowers
+    from distributed_tensorflow_amd.parallel.towers import DenseInGraphEngine, DenseInGraphTowers, InGraphEngine, InGraphTowers
 
     mnist = mnist_mlp.load_data(FLAGS)
     print("worker setting up ...", flush=True)
@@ -43,8 +43,13 @@ def main(_):
         crowded = n_gpu and max(devices.count(d) for d in devices) > 2
         exchange = "inbox" if (n_gpu and not crowded and FLAGS.activation == "sigmoid") else "rccl"
     hidden = mnist_mlp.hidden_widths(FLAGS)
-    if hidden != (100,):
-        # any other stack: the host-loop towers around the dense-layer engine (all-reduce of the towers' gradient slabs)
+    if hidden != (100,) and n_gpu and FLAGS.exchange != "rccl" and max(devices.count(d) for d in devices) <= 2:
+        # any other stack on GPUs: a stream and hipGraph chunks per tower, the stack's gradient launches and one
+        # exchange kernel per step (sum of the towers' gradient slabs through peer access + SGD)
+        towers = DenseInGraphEngine(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
+                                    hidden=hidden, act=FLAGS.activation, seed=1, chunk=min(50, int(FLAGS.freq)))
+    elif hidden != (100,):
+        # CPU towers, or --exchange rccl: the host-loop towers around the dense-layer engine (all-reduce of the slabs)
         towers = DenseInGraphTowers(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
                                     hidden=hidden, act=FLAGS.activation, seed=1)
     elif exchange == "inbox" and n_gpu:
