@@ -46,7 +46,10 @@ def define_hparam_flags():
     f.DEFINE_string("activation", "sigmoid", "hidden activation: sigmoid (reference), relu or tanh")
     f.DEFINE_string("hidden", "100", "widths of the hidden layers, comma-separated: 100 is the reference's network, "
                                      "e.g. 512,256 a deeper stack on the dense-layer kernels")
-    f.DEFINE_boolean("resident", False, "device-resident hipGraph loop instead of one sess.run per batch")
+    f.DEFINE_boolean("resident", False, "device-resident hipGraph loop instead of one sess.run per batch.  Synchronous "
+                     "replicas in this tier keep one replica per worker and sum EVERY worker's gradient inside their "
+                     "kernels: replicas_to_aggregate must equal total_num_replicas (backup workers, "
+                     "replicas_to_aggregate < total_num_replicas, run in the per-batch tier: tcp and ipc transports)")
     f.DEFINE_boolean("summaries", True, "write cost/accuracy summaries every step")
     f.DEFINE_integer("max_steps", 0, "stop after this many batches in total (0: run all epochs)")
     f.DEFINE_string("transport", "tcp", "parameter-server transport: tcp | ipc")

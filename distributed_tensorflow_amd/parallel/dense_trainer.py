@@ -477,7 +477,8 @@ class PsDenseSyncResidentTrainer:
         self.rank, self.world = sess.server.task_index, sess.server.num_workers
         if opt.replicas_to_aggregate != self.world or opt.total_num_replicas != self.world:
             raise ValueError("the resident synchronous tier aggregates every worker's gradient: "
-                             "replicas_to_aggregate and total_num_replicas must equal the number of workers")
+                             "replicas_to_aggregate and total_num_replicas must equal the number of workers "
+                             "(backup workers are served by the per-batch tier: run without --resident)")
         self.chunk = max(1, int(chunk))
         self.use_graph = bool(use_graph)
         layout = sess.layout
