@@ -645,10 +645,14 @@ __device__ __forceinline__ f32x4 smax_dz3(const SmaxIn& in, int tid, int M, int 
 }
 
 // NA = 16-row sub-tiles of dW1 per workgroup (tile = 16 NA rows x 16 columns).
-// Row stride of the backward tiles' cross-wave reduction image: 64 lanes + 4.  Rows are written lane by lane; with
-// out_map's transposed form a wave reads (4 registers) x (4 lane groups) x (4 columns) = rows r..r+3 at lanes
-// 16 g + c..c+3, i.e. banks 4 r + 16 g + c: 64 different ones.
-constexpr int kBwdRed = 68;
+// The backward tiles' cross-wave reduction image: one row per (wave, sub-tile, accumulator register), the wave's 64
+// lanes at positions redpos(lane) = lane + 8 * (lane >= 32), rows kBwdRed = 98 floats apart (2 modulo the 32 banks).
+// A row is written lane by lane: lanes 0-31 cover 32 banks, lanes 32-63 (positions 40-71) again 32 different ones.
+// With out_map's transposed form a 32-lane pass reads (4 registers) x (4 lane groups) x (2 columns): bank =
+// 2 reg + {0, 16, 8, 24}[lane group] + column -- 32 different ones (with plain 64- or 68-float rows lane groups g
+// and g + 2 met in the same banks: 2-way conflicts on every read, 22,700 of the step's 32,500 conflict cycles).
+constexpr int kBwdRed = 98;
+__device__ __forceinline__ int redpos(int lane) { return lane + ((lane >> 5) << 3); }
 constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * kBwdRed > 2 * 128 * kLdw ? 8 * NA * 4 * kBwdRed : 2 * 128 * kLdw; }
 // Output element o of a backward tile -> (16-row sub-tile, accumulator register, lane) of the reduction image.
 // Plain: a wave takes one (sub-tile, register) image, lane by lane (a store covers 4 rows x 64 bytes of W1[K][H]).
@@ -1093,7 +1097,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
 #pragma unroll
     for (int sa = 0; sa < NA; ++sa)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) red[(wave * 4 * NA + 4 * sa + g) * kBwdRed + lane] = acc[sa][g];
+      for (int g = 0; g < 4; ++g) red[(wave * 4 * NA + 4 * sa + g) * kBwdRed + redpos(lane)] = acc[sa][g];
     __syncthreads();
     DTF_STAMP2_AT(lin, 4);
     if constexpr (XG) {
@@ -1106,7 +1110,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + o_ln];
+        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + redpos(o_ln)];
         xown[0] = gs * s;
         if (is_main) {
           const int orow = k0 + o_trow, ocol = h0 + o_tcol;
@@ -1153,7 +1157,7 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
         const int o_trow = 16 * o_sub + 4 * (o_ln >> 4) + o_reg, o_tcol = o_ln & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + o_ln];
+        for (int w = 0; w < kBwdWaves; ++w) s += red[(w * 4 * NA + 4 * o_sub + o_reg) * kBwdRed + redpos(o_ln)];
         if (is_main) {
           const int orow = k0 + o_trow, ocol = h0 + o_tcol;
           if (orow < K && ocol < H) {
