@@ -13,32 +13,45 @@
 // it stores into the epoch-ordered copy, so the set is read once through the permutation instead of once by a
 // gather kernel and again by a batched GEMM.
 //
-// Work split.  A pair (j, j+1) is a [112 x 112 x K] product (B = 100 padded to 7 x 7 MFMA blocks).  Two
-// workgroups of 4 waves share a pair: half 0 owns block rows 0-3 (m < 64), half 1 block rows 4-6; wave w of a
-// workgroup accumulates ONE block row against all 7 block columns (28 accumulator registers), so a 16-k
-// macro-step costs a wave 1 + 7 LDS reads of 16 bytes for 28 MFMAs.  1,098 workgroups of unequal size (4 : 3)
-// spread over 256 CUs at up to 3 workgroups per CU; the two halves of a pair get block ids 8 apart, i.e. the
-// same XCD under round-robin dispatch, so the rows of batch j they both read meet in one L2.
+// Work split.  A pair (j, j+1) is a [112 x 112 x K] product (B = 100 padded to 7 x 7 MFMA blocks): 7 block rows of 16
+// Gram rows, "units" of 1,372 MFMAs, one wave each -- the wave accumulates its block row against all 7 block columns
+// (28 accumulator registers), and a 16-k macro-step costs it 1 + 7 LDS reads of 16 bytes for 28 MFMAs.  549 pairs
+// are 3,843 units; the chip has 1,024 SIMDs with room for 4 such waves each, so ALL units are resident at once:
+// workgroup w of 256 (16 waves, one workgroup per CU) takes units [w U / 256, (w + 1) U / 256) -- 15 or 16 of them
+// -- and every SIMD ends at the same time.  (Two workgroups of four waves per pair, the earlier split, ran 1,098
+// workgroups of unequal size through 768 slots: a ragged second round, and every row read three times.)
+// Consecutive units belong to at most 4 consecutive pairs, i.e. 5 consecutive batches, and a batch that is x_{j+1}
+// of one pair is x_j of the next: the workgroup stages each of its batches ONCE per chunk, as an image
+// [k-quad][116 rows][4 floats], and every wave reads its 16 A rows from one image and the 7 x 16 B rows from the
+// image before it.  Rows are read ~1.6x (the batches at a workgroup's ends are also its neighbours', and neighbours
+// share an XCD and its L2).
 //
-// Staging.  K is walked in chunks of 64 floats (16 k-quads).  A wave-instruction loads 8 rows x 8 k-quads:
-// lanes 0-7 take the same k-quad of 8 consecutive rows, so every touched 128-byte line is used whole and the
-// eight lanes of an LDS store group write 128 contiguous bytes.  The LDS image is [k-quad][row][4 floats] with
-// 64 / 112 rows per k-quad: lane (i = l & 15, q = l >> 4) of a macro-step reads k-quad 4 ms + q of row i as one
-// ds_read_b128, and the 16 lanes of every ds_read_b128 lane group cover 16 different rows of (at most two)
-// k-quads whose row counts are multiples of 16 -- 16 distinct 16-byte slots, no bank conflict.  MFMA s of the
-// macro-step contracts k = 16 ms + 4 q + s (component s of both operands).  One LDS buffer and one register set:
-// the loads of chunk c+1 are issued right after chunk c was written to LDS and land while chunk c is multiplied.
+// Staging.  K is walked in chunks of 64 floats (16 k-quads).  A wave-instruction loads 4 rows x 16 k-quads (256
+// contiguous bytes of each row) with lane -> (row l & 3, k-quad l >> 2); 25 row groups per batch, at most 125 of
+// them per workgroup and chunk = 8 loads per thread.  Rows per k-quad are padded to 116 so that consecutive
+// k-quads lie 16 banks apart: the 8 lanes of a ds_write_b128 group (4 rows of 2 k-quads) cover all 32 banks.  Lane
+// (i = l & 15, q = l >> 4) of a macro-step reads k-quad 4 ms + q of row i as one ds_read_b128: the 16 lanes of a
+// lane group read 256 contiguous bytes, no bank conflict.  MFMA s of the macro-step contracts k = 16 ms + 4 q + s
+// (component s of both operands).  Rows B..115 of an image are never written: Gram element (m, i) depends on A row
+// m and B row i alone, and rows or columns beyond B are not stored.  One LDS buffer and one register set: the loads
+// of chunk c+1 are issued while chunk c is multiplied, into the registers whose rows of chunk c have just been
+// stored.  The row that a thread loads is also the row it stores into the epoch-ordered copy if the row's unit (as
+// x_{j+1}) is one of the workgroup's (batch 0: the workgroup that owns unit 0).
 #include "dtf_api.h"
 #include "dtf_common.h"
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kChunkQ = 16;                 // k-quads per chunk (64 floats)
-constexpr int kRowsA = 64;                  // rows of batch j+1 per workgroup (4 block rows)
-constexpr int kRowsB = 112;                 // rows of batch j in the LDS image (7 block columns)
-constexpr int kRowGroups = (kRowsA + 104) / 8;   // 8 groups of A rows + 13 groups of B rows (104 >= 100)
-constexpr int kLoads = (kRowGroups * 2 + 3) / 4; // wave-instructions per wave and chunk (11)
+constexpr int kRowsB = 112;                 // Gram columns with padding (7 block columns): the largest leading dimension
+constexpr int kPThreads = 1024;
+constexpr int kPWaves = kPThreads / 64;
+constexpr int kPRows = 116;                 // rows per k-quad of a batch image
+constexpr int kPMaxBat = 5;                 // batches that 16 consecutive units can touch
+constexpr int kPBat = kChunkQ * kPRows * 4; // floats per batch image (29,696 bytes)
+constexpr int kPLoads = 8;                  // wave-instructions per wave and chunk
+constexpr int kBlk = 7;                     // MFMA block rows (and columns) of a pair
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GramArgs {
   const float* src;        // [rows_src][K] master copy
@@ -53,150 +66,183 @@ struct GramArgs {
   int parts;               // timing experiments: bit 0 global loads per chunk, bit 1 products, bit 2 row stores (7: all)
 };
 
-__global__ __launch_bounds__(kThreads, 3) void gather_gram_kernel(GramArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[kChunkQ * kRowsA * 4];
-  __shared__ __attribute__((aligned(16))) float Bs[kChunkQ * kRowsB * 4];
+__global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
+  __shared__ __attribute__((aligned(16))) float img[kPMaxBat * kPBat];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  // Blocks b and b + 8 share an XCD under round-robin dispatch.  An XCD walks a CONTIGUOUS range of pairs in
-  // dispatch order, both halves of a pair back to back: the rows of batch j are wanted by pair j - 1 (as x_{j+1})
-  // and by both halves of pair j (as x_j), and workgroups that run side by side on one XCD find them in its L2.
-  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-  const int npairs = a.nb - 1;
-  const int per_xcd = (npairs + 7) >> 3;
-  const int pair = xcd * per_xcd + (slot >> 1), half = slot & 1;
-  if ((slot >> 1) >= per_xcd || pair >= npairs) return;
+  // blocks b and b + 8 share an XCD under round-robin dispatch: an XCD gets a contiguous range of workgroups, whose
+  // end batches are the neighbours' too and meet in its L2
+  const int per_x = (int)gridDim.x >> 3;
+  const int wg = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
+  const long U = (long)(a.nb - 1) * kBlk;
+  const int u0 = (int)(wg * U / (long)gridDim.x), u1 = (int)((wg + 1) * U / (long)gridDim.x);
+  if (u0 >= u1) return;
+  const int b0 = u0 / kBlk, b1 = (u1 - 1) / kBlk + 1;         // batches b0 .. b1 (b1: as x_{j+1} only)
+  const int nbat = b1 - b0 + 1;
   const int B = a.B, K = a.K, nkq = K >> 2;
-  const int m_base = half * kRowsA;                   // first batch row of this workgroup's A rows
-
-  // ---- the rows this thread loads: row group rg = 2 u + (wave >> 1), k-quad group kg = wave & 1 -----------
-  // (rg, and with it everything but the row-within-group term, is wave-uniform: only the source offsets, which
-  // come through the permutation, are kept per load in vector registers)
-  const int r8 = lane & 7, kql = lane >> 3;           // row within the group, k-quad within the group
-  const int kg = wave & 1, rg0 = wave >> 1;
+  const int ngroups = (B + 3) >> 2;
+  const int r4 = lane & 3, kql = lane >> 2;
   const unsigned rowbytes = (unsigned)K * 4u;
-  const unsigned dstA = (unsigned)(((long)(pair + 1) * B + m_base + r8) * (long)rowbytes);   // + 8 rg rows
-  const unsigned dstB = (unsigned)(((long)pair * B + r8) * (long)rowbytes);                  // + 8 (rg - 8) rows
-  const unsigned ldsA = (unsigned)(((kql + 8 * kg) * kRowsA + r8) * 4);                      // + 32 rg floats
-  const unsigned ldsB = (unsigned)(((kql + 8 * kg) * kRowsB + r8) * 4);                      // + 32 (rg - 8) floats
-  const bool store_b = pair == 0 && half == 0;        // batch 0 is nobody's "j + 1": pair 0 stores it
-  unsigned srcoff[kLoads];      // byte offset of the source row (through the permutation)
+#define DTF_GRAM_OWNS(batch, blockrow) \
+  (((batch) >= 1 && ((batch) - 1) * kBlk + (blockrow) >= u0 && ((batch) - 1) * kBlk + (blockrow) < u1) || ((batch) == 0 && u0 == 0))
+
+  // ---- the rows this thread loads: item = wave + 16 u -> (batch slot, group of 4 rows); wave-uniform -------------
+  // Everything a chunk does with memory is branch-free, so that its loads, LDS writes and stores sit in straight-line
+  // code and the compiler counts the outstanding memory operations exactly (with a branch around every load and
+  // store it waited for vmcnt(0) before each of them: sixteen memory round trips in a row per chunk).  Loads and
+  // stores go through buffer descriptors and an item that is not wanted gets an offset beyond the buffer: the range
+  // check drops the store and returns zeros for the load (also for k-quads beyond K in the last chunk).
+  const unsigned src_bytes = (unsigned)a.rows_src * rowbytes, dst_bytes = a.dst != nullptr ? (unsigned)(a.nb * B) * rowbytes : 0u;
+  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), (short)0, (int)src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.dst, (short)0, (int)((a.parts & 4) ? dst_bytes : 0u), 0x00020000);
+  constexpr unsigned kBeyond = 0xffffffffu;
+  unsigned srcoff[kPLoads];                                   // byte offset of the source row; kBeyond: no load
+  int ldsoff[kPLoads];                                        // wave-uniform: the group's first row in img, in units of 16 floats
+  unsigned dstrow[kPLoads];                                   // wave-uniform: epoch row of the group's first row
+  unsigned own = 0;                                           // bit u: the rows of item u are stored by this workgroup
 #pragma unroll
-  for (int u = 0; u < kLoads; ++u) {
-    const int rg = 2 * u + rg0;
-    const bool isA = rg < kRowsA / 8;
-    const int brow = isA ? m_base + 8 * rg + r8 : 8 * (rg - kRowsA / 8) + r8;     // row inside its batch
-    const bool ok = rg < kRowGroups && brow < B;
-    const long erow = (long)(pair + (isA ? 1 : 0)) * B + (ok ? brow : 0);         // row of the epoch order
+  for (int u = 0; u < kPLoads; ++u) {
+    const int it = wave + kPWaves * u;
+    const int bs = it / ngroups, rg = it - bs * ngroups;
+    const int batch = b0 + bs;
+    const bool owned = bs < nbat && DTF_GRAM_OWNS(batch, rg >> 2);
+    const bool needed = bs < nbat && (batch < b1 || owned);   // every row of a batch that is some pair's x_j here
+    own |= (owned ? 1u : 0u) << u;
+    // an item beyond the workgroup's batches writes its zeros into rows that no product keeps (4 ngroups .. + 3 >= B)
+    ldsoff[u] = bs < nbat ? bs * (kPBat / 16) + rg : ngroups;
+    dstrow[u] = (unsigned)(batch * B + 4 * rg);
+    const int row = 4 * rg + r4;
+    const long erow = needed ? (long)batch * B + (row < B ? row : 0) : 0;
     long srow = a.perm[erow];
     srow = srow < 0 ? 0 : (srow >= a.rows_src ? a.rows_src - 1 : srow);            // never outside the master copy
-    srcoff[u] = (unsigned)(srow * (long)rowbytes);
-  }
-  // rows 104-111 of the B image are never loaded: zero them once (rows 100-103 are written as zeros per chunk)
-  for (int e = tid; e < kChunkQ * 8; e += kThreads) {
-    const int kq = e >> 3, r = 104 + (e & 7);
-    *reinterpret_cast<f32x4*>(Bs + (kq * kRowsB + r) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    srcoff[u] = (needed && row < B) ? (unsigned)(srow * (long)rowbytes) : kBeyond;
   }
 
-  // the labels of the rows this workgroup stores travel with them (one element per thread and turn)
+  const int nchunks = (nkq + kChunkQ - 1) / kChunkQ;
+  const int nkq_ld = (a.parts & 1) ? nkq : 0;
+  f32x4 stage[kPLoads];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < kPLoads; ++u) {
+    const unsigned off = (kql < nkq_ld && srcoff[u] != kBeyond) ? srcoff[u] + (unsigned)kql * 16u : kBeyond;
+    stage[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0));
+  }
+
+  f32x4 acc[kBlk];
+#pragma unroll
+  for (int bi = 0; bi < kBlk; ++bi) acc[bi] = zero4;
+  const bool wave_works = u0 + wave < u1;
+  const int unit = wave_works ? u0 + wave : u0;
+  const int pair = unit / kBlk, brow = unit - pair * kBlk;
+  const float* As = img + (pair + 1 - b0) * kPBat + (16 * brow + i16) * 4;
+  const float* Bs = img + (pair - b0) * kPBat + i16 * 4;
+
+  // the labels of the rows this workgroup stores travel with them, behind the first chunk's loads: a wave takes the
+  // 16 rows of its own unit, four elements per lane at a time so that the loads of a turn are in flight together
   if (a.ydst != nullptr) {
     const int C = a.C;
-    const int rowsA = B - m_base < kRowsA ? B - m_base : kRowsA;
-    for (int e = tid; e < rowsA * C; e += kThreads) {
-      const long erow = (long)(pair + 1) * B + m_base + e / C;
-      long srow = a.perm[erow];
-      srow = srow < 0 ? 0 : (srow >= a.rows_src ? a.rows_src - 1 : srow);
-      a.ydst[erow * C + e % C] = a.ysrc[srow * C + e % C];
+    if (wave_works) {
+      const long erow0 = (long)(pair + 1) * B + 16 * brow;
+      const int n = (B - 16 * brow < 16 ? B - 16 * brow : 16) * C;
+      for (int e0 = 0; e0 < n; e0 += 256) {
+        long srow[4];
+        int row[4];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + lane + 64 * j;
+          row[j] = e < n ? e / C : 0;
+          srow[j] = a.perm[erow0 + row[j]];
+          srow[j] = srow[j] < 0 ? 0 : (srow[j] >= a.rows_src ? a.rows_src - 1 : srow[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + lane + 64 * j;
+          v[j] = a.ysrc[srow[j] * C + (e < n ? e - row[j] * C : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + lane + 64 * j;
+          if (e < n) a.ydst[(erow0 + row[j]) * C + (e - row[j] * C)] = v[j];
+        }
+      }
     }
-    if (store_b)
-      for (int e = tid; e < B * C; e += kThreads) {
+    if (u0 == 0)                                        // batch 0 is nobody's x_{j+1}
+      for (int e = tid; e < B * C; e += kPThreads) {
         long srow = a.perm[e / C];
         srow = srow < 0 ? 0 : (srow >= a.rows_src ? a.rows_src - 1 : srow);
         a.ydst[e] = a.ysrc[srow * C + e % C];
       }
   }
 
-  const char* src = reinterpret_cast<const char*>(a.src);
-  char* dst = reinterpret_cast<char*>(a.dst);
-  const int nchunks = (nkq + kChunkQ - 1) / kChunkQ;
-  f32x4 stage[kLoads];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#define DTF_GRAM_ISSUE(c)                                                                           \
-  do {                                                                                              \
-    const int kq_ = (c) * kChunkQ + 8 * kg + kql;                                                   \
-    const unsigned koff_ = (unsigned)((kq_ < nkq ? kq_ : 0) * 16);                                  \
-    _Pragma("unroll") for (int u = 0; u < kLoads; ++u)                                              \
-        stage[u] = *reinterpret_cast<const f32x4*>(src + srcoff[u] + koff_);                        \
-  } while (0)
-  DTF_GRAM_ISSUE(0);
-
-  f32x4 acc[7];
-#pragma unroll
-  for (int bi = 0; bi < 7; ++bi) acc[bi] = zero4;
-  const bool wave_works = m_base + 16 * wave < B;     // half 1: block row 7 does not exist
-
   for (int c = 0; c < nchunks; ++c) {
-    const int kq = c * kChunkQ + 8 * kg + kql;
-    const bool kq_ok = kq < nkq;
+    const int kq = c * kChunkQ + kql;
     __syncthreads();                                  // the previous chunk has been multiplied
 #pragma unroll
-    for (int u = 0; u < kLoads; ++u) {
-      const int rg = 2 * u + rg0;                     // wave-uniform
-      if (rg >= kRowGroups) continue;
-      const bool isA = rg < kRowsA / 8;
-      const int rgl = isA ? rg : rg - kRowsA / 8;
-      const bool ok = (isA ? m_base + 8 * rgl + r8 : 8 * rgl + r8) < B;
-      const f32x4 v = (ok && kq_ok) ? stage[u] : zero4;
-      *reinterpret_cast<f32x4*>((isA ? As + ldsA : Bs + ldsB) + 32 * rgl) = v;
-    }
+    for (int u = 0; u < kPLoads; ++u)
+      *reinterpret_cast<f32x4*>(img + 16 * ldsoff[u] + (kql * kPRows + r4) * 4) = stage[u];
     __syncthreads();
-    // the epoch-ordered copy: stored from the staging registers AFTER the barrier, so that no wave waits at the
-    // barrier for another wave's global stores (the registers are reloaded right below); streaming stores: 172 MB
-    // that nobody reads before the kernel ends (loads + stores alone 134 -> 97 us)
-    if (a.dst != nullptr && (a.parts & 4) && kq_ok) {
-#pragma unroll
-      for (int u = 0; u < kLoads; ++u) {
-        const int rg = 2 * u + rg0;
-        if (rg >= kRowGroups) continue;
-        const bool isA = rg < kRowsA / 8;
-        const int rgl = isA ? rg : rg - kRowsA / 8;
-        const bool ok = (isA ? m_base + 8 * rgl + r8 : 8 * rgl + r8) < B;
-        if (ok && (isA || store_b))
-          __builtin_nontemporal_store(stage[u], reinterpret_cast<f32x4*>(dst + (isA ? dstA : dstB) + (unsigned)(8 * rgl) * rowbytes + (unsigned)kq * 16u));
-      }
+    // The epoch-ordered copy is stored from the staging registers AFTER the barrier (no wave waits at the barrier for
+    // another wave's global stores; streaming stores: nobody reads the copy before the kernel ends), and the loads
+    // of the next chunk follow into the same registers (beyond K: out of range, no traffic).  All 16 waves leave the
+    // barrier together: were they to issue their 16 memory instructions there, the matrix pipes would idle until the
+    // address unit has taken 256 KB of them.  A full chunk therefore starts with the products of macro-step 0 and
+    // issues half of its memory instructions before macro-step 1 and half before macro-step 2, by which time the
+    // waves of a SIMD are staggered by the shared matrix pipe and one wave's memory instructions overlap the
+    // others' products (136 -> 128 us).
+    const unsigned lane_off = (unsigned)r4 * rowbytes + (unsigned)kq * 16u;
+    const int kq_next = kq + kChunkQ;
+#define DTF_GRAM_MEM(U0, U1)                                                                                       \
+  _Pragma("unroll") for (int u = (U0); u < (U1); ++u) {                                                           \
+    const bool st_ = (own >> u & 1u) && kq < nkq && srcoff[u] != kBeyond; /* srcoff: the row exists (< B) */      \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, stage[u]), dst_rsrc,                         \
+                                           st_ ? dstrow[u] * rowbytes + lane_off : kBeyond, 0, 2);                \
+  }                                                                                                                \
+  _Pragma("unroll") for (int u = (U0); u < (U1); ++u) {                                                           \
+    const unsigned off_ = (kq_next < nkq_ld && srcoff[u] != kBeyond) ? srcoff[u] + (unsigned)kq_next * 16u : kBeyond; \
+    stage[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off_, 0, 0));            \
+  }
+    // B operands in two turns (4 + 3 blocks): 12 registers fewer than all seven at once
+#define DTF_GRAM_MACRO(ms)                                                                                         \
+  do {                                                                                                             \
+    const f32x4 av = *reinterpret_cast<const f32x4*>(As + (4 * (ms) + q) * kPRows * 4);                            \
+    f32x4 bv[4];                                                                                                   \
+    _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                                               \
+        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + ((4 * (ms) + q) * kPRows + 16 * bi) * 4);                    \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                 \
+        acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[bi][s], acc[bi], 0, 0, 0);                        \
+    _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                                                               \
+        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + ((4 * (ms) + q) * kPRows + 16 * (4 + bi)) * 4);              \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                 \
+        acc[4 + bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[bi][s], acc[4 + bi], 0, 0, 0);                \
+  } while (0)
+    const int left = nkq - c * kChunkQ;
+    const int nms = !(wave_works && (a.parts & 2)) ? 0 : (left >= kChunkQ ? 4 : (left + 3) >> 2);
+    if (nms < 4) {
+      DTF_GRAM_MEM(0, kPLoads)
     }
-    if (c + 1 < nchunks && (a.parts & 1)) DTF_GRAM_ISSUE(c + 1);       // lands while this chunk is multiplied
-    if (wave_works && (a.parts & 2)) {
-      const int left = nkq - c * kChunkQ;
-      const int nms = left >= kChunkQ ? 4 : (left + 3) >> 2;
 #pragma unroll 1
-      for (int ms = 0; ms < nms; ++ms) {
-        {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(As + ((4 * ms + q) * kRowsA + 16 * wave + i16) * 4);
-          f32x4 bv[7];
-#pragma unroll
-          for (int bi = 0; bi < 7; ++bi)
-            bv[bi] = *reinterpret_cast<const f32x4*>(Bs + ((4 * ms + q) * kRowsB + 16 * bi + i16) * 4);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int bi = 0; bi < 7; ++bi)
-              acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[bi][s], acc[bi], 0, 0, 0);
-        }
+    for (int ms = 0; ms < nms; ++ms) {              // (rolled: unrolled, the macro-steps overlap and spill)
+      if (nms == 4 && ms == 1) {
+        DTF_GRAM_MEM(0, kPLoads / 2)
       }
+      if (nms == 4 && ms == 2) {
+        DTF_GRAM_MEM(kPLoads / 2, kPLoads)
+      }
+      DTF_GRAM_MACRO(ms);
     }
   }
 
-  // ---- epilogue: D[row = 4 q + reg][col = i16] of block (wave, bi) -> gram[pair][m][i] ---------------------
+  // ---- epilogue: D[row = 4 q + reg][col = i16] of block (brow, bi) -> gram[pair][m][i] ---------------------------
   if (wave_works) {
     float* g = a.gram + (size_t)pair * B * a.ld;
 #pragma unroll
-    for (int bi = 0; bi < 7; ++bi) {
+    for (int bi = 0; bi < kBlk; ++bi) {
       const int i = 16 * bi + i16;
       if (i >= a.ld) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m_base + 16 * wave + 4 * q + r;
+        const int m = 16 * brow + 4 * q + r;
         if (m < B) g[(size_t)m * a.ld + i] = i < B ? 1.0f + acc[bi][r] : 0.f;
       }
     }
@@ -223,19 +269,25 @@ extern "C" int dtf_gather_gram(const float* src, const int64_t* perm, float* dst
   if (!dtf_gather_gram_supported(B, K) || nb < 2 || ld < B || ld > kRowsB || (ld & 15) || rows_src < 1)
     return DTF_ERR_SHAPE;
   if (!aligned16(src) || (dst && !aligned16(dst)) || !aligned16(gram)) return DTF_ERR_SHAPE;
-  if ((long)rows_src * K * 4 >= (1L << 32) || (long)nb * B * K * 4 >= (1L << 32)) return DTF_ERR_SHAPE;
+  // byte offsets are 32-bit, and 0xffffffff means "no access": a row's offset plus an offset inside a row must stay below it
+  if (((long)rows_src + 1) * K * 4 >= (1L << 32) - 1 || ((long)nb * B + 1) * K * 4 >= (1L << 32) - 1) return DTF_ERR_SHAPE;
   if ((ysrc == nullptr) != (ydst == nullptr) || (ydst && C < 1)) return DTF_ERR_NULL;
   GramArgs a{src, perm, dst, gram, B, K, nb, ld, rows_src, ysrc, ydst, C, g_gram_parts};
-  const int npairs = nb - 1;
-  const int blocks = 2 * ((npairs + 7) / 8) * 8;
-  hipLaunchKernelGGL(gather_gram_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, a);
+  // a workgroup's units: at most 16 (one per wave), and few enough that its batches' row groups fit 8 loads a thread
+  // (16 units touch at most 5 batches of 25 row groups, 15 units at most 4 batches of 26)
+  const long units = (long)(nb - 1) * kBlk;
+  const int max_units = B <= 100 ? kPWaves : kPWaves - 1;
+  long wgs = units >= 256 * 8 ? 256 : (units + 7) / 8;
+  if (wgs * max_units < units) wgs = (units + max_units - 1) / max_units;
+  const int blocks = (int)((wgs + 7) / 8 * 8);
+  hipLaunchKernelGGL(gather_gram_kernel, dim3(blocks), dim3(kPThreads), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
 // Workgroups of the kernel that one CU holds at a time, as the runtime computes it (registers, LDS, wave slots).
 extern "C" int dtf_debug_gram_blocks_per_cu(void) {
   int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gram_kernel, kThreads, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_gram_kernel, kPThreads, 0) != hipSuccess) return -1;
   return n;
 }
 

@@ -646,13 +646,13 @@ __device__ __forceinline__ f32x4 smax_dz3(const SmaxIn& in, int tid, int M, int 
 
 // NA = 16-row sub-tiles of dW1 per workgroup (tile = 16 NA rows x 16 columns).
 // The backward tiles' cross-wave reduction image: one row per (wave, sub-tile, accumulator register), the wave's 64
-// lanes at positions redpos(lane) = lane + 8 * (lane >= 32), rows kBwdRed = 98 floats apart (2 modulo the 32 banks).
-// A row is written lane by lane: lanes 0-31 cover 32 banks, lanes 32-63 (positions 40-71) again 32 different ones.
+// lanes at positions redpos(lane) = lane + 2 * (lane >= 32), rows kBwdRed = 68 floats apart (4 modulo the 32 banks).
+// A row is written lane by lane: lanes 0-31 cover 32 banks, lanes 32-63 (positions 34-65) again 32 different ones.
 // With out_map's transposed form a 32-lane pass reads (4 registers) x (4 lane groups) x (2 columns): bank =
-// 2 reg + {0, 16, 8, 24}[lane group] + column -- 32 different ones (with plain 64- or 68-float rows lane groups g
+// 4 reg + {0, 16, 2, 18}[lane group] + column -- 32 different ones (with the lanes at positions 0-63 lane groups g
 // and g + 2 met in the same banks: 2-way conflicts on every read, 22,700 of the step's 32,500 conflict cycles).
-constexpr int kBwdRed = 98;
-__device__ __forceinline__ int redpos(int lane) { return lane + ((lane >> 5) << 3); }
+constexpr int kBwdRed = 68;
+__device__ __forceinline__ int redpos(int lane) { return lane + ((lane >> 5) << 1); }
 constexpr int bwd16_red_floats(int NA) { return 8 * NA * 4 * kBwdRed > 2 * 128 * kLdw ? 8 * NA * 4 * kBwdRed : 2 * 128 * kLdw; }
 // Output element o of a backward tile -> (16-row sub-tile, accumulator register, lane) of the reduction image.
 // Plain: a wave takes one (sub-tile, register) image, lane by lane (a store covers 4 rows x 64 bytes of W1[K][H]).
