@@ -64,6 +64,7 @@ struct GramArgs {
   float* ydst;
   int C;
   int parts;               // timing experiments: bit 0 global loads per chunk, bit 1 products, bit 2 row stores (7: all)
+  long long* stamps;       // timing experiments: [workgroup][24] wall-clock stamps (100 MHz) of wave 0, or null
 };
 
 __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
   const int ngroups = (B + 3) >> 2;
   const int r4 = lane & 3, kql = lane >> 2;
   const unsigned rowbytes = (unsigned)K * 4u;
+#define DTF_GRAM_STAMP(i) \
+  if (a.stamps != nullptr && tid == 0) a.stamps[(long)wg * 24 + (i)] = wall_clock64()
+  DTF_GRAM_STAMP(0);
 #define DTF_GRAM_OWNS(batch, blockrow) \
   (((batch) >= 1 && ((batch) - 1) * kBlk + (blockrow) >= u0 && ((batch) - 1) * kBlk + (blockrow) < u1) || ((batch) == 0 && u0 == 0))
 
@@ -175,9 +179,11 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
       }
   }
 
+  DTF_GRAM_STAMP(1);
   for (int c = 0; c < nchunks; ++c) {
     const int kq = c * kChunkQ + kql;
     __syncthreads();                                  // the previous chunk has been multiplied
+    if (c < 20) DTF_GRAM_STAMP(2 + c);
 #pragma unroll
     for (int u = 0; u < kPLoads; ++u)
       *reinterpret_cast<f32x4*>(img + 16 * ldsoff[u] + (kql * kPRows + r4) * 4) = stage[u];
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
     }
   }
 
+  DTF_GRAM_STAMP(22);
   // ---- epilogue: D[row = 4 q + reg][col = i16] of block (brow, bi) -> gram[pair][m][i] ---------------------------
   if (wave_works) {
     float* g = a.gram + (size_t)pair * B * a.ld;
@@ -247,9 +254,11 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
       }
     }
   }
+  DTF_GRAM_STAMP(23);
 }
 
 int g_gram_parts = 7;
+long long* g_gram_stamps = nullptr;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -272,7 +281,7 @@ extern "C" int dtf_gather_gram(const float* src, const int64_t* perm, float* dst
   // byte offsets are 32-bit, and 0xffffffff means "no access": a row's offset plus an offset inside a row must stay below it
   if (((long)rows_src + 1) * K * 4 >= (1L << 32) - 1 || ((long)nb * B + 1) * K * 4 >= (1L << 32) - 1) return DTF_ERR_SHAPE;
   if ((ysrc == nullptr) != (ydst == nullptr) || (ydst && C < 1)) return DTF_ERR_NULL;
-  GramArgs a{src, perm, dst, gram, B, K, nb, ld, rows_src, ysrc, ydst, C, g_gram_parts};
+  GramArgs a{src, perm, dst, gram, B, K, nb, ld, rows_src, ysrc, ydst, C, g_gram_parts, g_gram_stamps};
   // a workgroup's units: at most 16 (one per wave), and few enough that its batches' row groups fit 8 loads a thread
   // (16 units touch at most 5 batches of 25 row groups, 15 units at most 4 batches of 26)
   const long units = (long)(nb - 1) * kBlk;
@@ -293,3 +302,6 @@ extern "C" int dtf_debug_gram_blocks_per_cu(void) {
 
 // Timing experiments: run only some parts of the kernel (results are then wrong); 7 restores the full kernel.
 extern "C" void dtf_debug_set_gram_parts(int parts) { g_gram_parts = parts; }
+// Timing experiments: wave 0 of workgroup w writes wall-clock stamps to stamps[w][24] (0 start, 1 before the chunk loop,
+// 2 + c after the first barrier of chunk c, 22 after the loop, 23 at the end); null switches them off.
+extern "C" void dtf_debug_set_gram_stamps(void* stamps) { g_gram_stamps = static_cast<long long*>(stamps); }
