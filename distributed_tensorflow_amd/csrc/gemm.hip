@@ -12,12 +12,12 @@
 // (the MatMul, BiasAdd, Sigmoid / Relu, their gradients and ApplyGradientDescent of a graph built like
 // tfdist_between.py:55-66, for any number of layers).
 //
-// Tiling.  A workgroup of four waves owns a BM x BN tile of C (128 x 128, or 64 x 64 when the larger tile would leave
-// CUs idle) and walks K in chunks of 32.  Both operands of a chunk sit in LDS as [k-quad][row or column][4 floats]
+// Tiling.  A workgroup owns a BM x BN tile of C (128 x 128 with four waves, or 64 x 64 with eight when the larger tile
+// would leave CUs idle) and walks K in chunks of 32.  Both operands of a chunk sit in LDS as [k-quad][row or column][4 floats]
 // images, so that lane (i = l & 15, q = l >> 4) reads the four k of k-quad 4 ms + q for row / column i with ONE
 // ds_read_b128 (16 lanes = 256 contiguous bytes: no bank conflict) and feeds them to four v_mfma_f32_16x16x4_f32: MFMA s
-// of macro-step ms contracts k = 16 ms + 4 q + s.  A wave computes a (BM/2) x (BN/2) quadrant: 8 reads for 64 MFMAs per
-// macro-step with the 128-tile.  Two chunk images: the loads of chunk c + 1 are requested before chunk c is multiplied
+// of macro-step ms contracts k = 16 ms + 4 q + s.  A wave computes a (BM/2) x (BN/2) quadrant of the 128-tile: 8 reads for 64 MFMAs
+// per macro-step (32 x 16 of the 64-tile: 3 reads for 8 MFMAs).  Two chunk images: the loads of chunk c + 1 are requested before chunk c is multiplied
 // and written to the other image after it; one barrier per chunk.
 //
 // Staging.  An operand whose k runs along memory (A of NN / NT, B of NT) arrives as 16-byte loads, 8 rows x 8 k-quads
@@ -205,12 +205,15 @@ struct Stager {
 };
 
 template <int BM, int BN, int LAYOUT, bool VEC, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(GemmArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr bool AK = LAYOUT != DTF_GEMM_TN, BK = LAYOUT == DTF_GEMM_NT;
   constexpr int kThreads = NW * 64;
-  // The waves of a workgroup tile its output 2 x 2 (four waves) or 2 x 4 (eight waves).  Only four are instantiated:
-  // eight waves on the 128-tile (four per SIMD with two workgroups per CU, 128 registers each) measured 108 - 120 TFLOP/s
-  // against 117 - 126 with four, and did not fit its registers.
+  // The waves of a workgroup tile its output 2 x 2 (four waves: the 128-tile) or 2 x 4 (eight waves: the 64-tile).
+  // Eight waves on the 128-tile (four per SIMD with two workgroups per CU, 128 registers each) measured 108 - 120 TFLOP/s
+  // against 117 - 126 with four, and did not fit its registers.  The 64-tile is what shapes with few tiles get, often ONE
+  // workgroup per CU: with four waves that is one wave per SIMD, whose matrix instructions do not follow each other
+  // without gaps (the K loop with everything but its MFMAs switched off: 115 TFLOP/s); eight waves put two on every
+  // SIMD -- 1024^3 NN 28.7 -> 24.9 us, 8192 x 128 x 2048 NN 49.5 -> 44.7 us, 100 x 1024 x 784 TN 13.4 -> 11.2 us.
   constexpr int WGN = NW / 2;
   constexpr int TM = BM / 32, TN = BN / (16 * WGN);    // 16 x 16 blocks per wave in each direction
   constexpr int kAs = kKQ * BM * 4, kBs = kKQ * BN * 4;
@@ -237,8 +240,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
   const int i16 = lane & 15, q = lane >> 4;
   const int wm0 = (wave / WGN) * (BM / 2), wn0 = (wave % WGN) * (BN / WGN);
 
-  // Chunks in flight between memory and LDS.  Two or three for the small tile (-DDTF_GEMM_DEPTH64=2|3) measured the
-  // same as one (100 x 784 x 1024: 37 us with each): a chunk of the small tile is not waiting for memory.
+  // Chunks in flight between memory and LDS.  Two, three or four for the small tile (-DDTF_GEMM_DEPTH64=2|3|4, pinned
+  // chunks D at a time) measured the same as one or a little worse (10000 x 100 x 784 NT: 32.8 / 33.3 / 35.0 / 35.5 us,
+  // 8192 x 128 x 784 NT: 20.3 / 19.7 / 20.9 / 21.5 us): a chunk of the small tile is not waiting for memory.
   constexpr int D = BM <= 64 ? DTF_GEMM_DEPTH64 : 1;
   Stager<BM, AK, VEC, D, NW> sa;
   Stager<BN, BK, VEC, D, NW> sb;
@@ -391,16 +395,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_f32_kernel(Gemm
     sa.template issue<3 % D>((cbeg + 3) * kChunk);
     sb.template issue<3 % D>((cbeg + 3) * kChunk);
   }
+  if (D > 3 && nchunks > 4) {
+    sa.template issue<4 % D>((cbeg + 4) * kChunk);
+    sb.template issue<4 % D>((cbeg + 4) * kChunk);
+  }
   __syncthreads();
   read_ops(As, Bs, 0, av[0], bv[0]);
   {
     int c = 0;
-    if (D == 1)                 // the steady state: pinned chunks (one register set: the parity plays no role)
-      for (; fast_ok(c); ++c) chunk_fast(c, std::integral_constant<int, 0>{});
-    for (; c < nchunks; c += D) {       // the last chunks, edge tiles, deeper prefetch: the same steps under conditions
+    // the steady state: pinned chunks, D at a time (chunk c + i works with register set (c + i + 1) % D)
+    for (; fast_ok(c + D - 1); c += D) {
+      chunk_fast(c, std::integral_constant<int, 0>{});
+      if constexpr (D > 1) chunk_fast(c + 1, std::integral_constant<int, 1 % D>{});
+      if constexpr (D > 2) chunk_fast(c + 2, std::integral_constant<int, 2 % D>{});
+      if constexpr (D > 3) chunk_fast(c + 3, std::integral_constant<int, 3 % D>{});
+    }
+    for (; c < nchunks; c += D) {       // the last chunks: the same steps under conditions
       chunk(c, std::integral_constant<int, 0>{});
       if (D > 1 && c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1 % D>{});
       if (D > 2 && c + 2 < nchunks) chunk(c + 2, std::integral_constant<int, 2 % D>{});
+      if (D > 3 && c + 3 < nchunks) chunk(c + 3, std::integral_constant<int, 3 % D>{});
     }
   }
 
@@ -525,7 +539,19 @@ int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
   const long small = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   const double t_big = (double)((big + 511) / 512), t_small = 0.55 * (double)((small + 1023) / 1024);
   if (tile == 128 || (tile == 0 && big >= 512 && t_big <= t_small)) return launch_gemm<128, 128, LAYOUT, VEC, 4>(a, stream);
-  return launch_gemm<64, 64, LAYOUT, VEC>(a, stream);
+  // Between one and one and a half small tiles per CU (10000 x 100 x 784: 314 of them), the CUs with two set the time;
+  // tiles of half the height spread the same work as three per CU at most: 32.7 -> 27.8 us there (NT).  Not for TN,
+  // whose A arrives strided: a strided operand wants at least 64 rows or columns per tile (a wave's 64 lanes share one
+  // k-quad), and not where K is split (few tiles).
+  if (LAYOUT != DTF_GEMM_TN) {
+    const long half = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
+    const long load_small = (small + 255) / 256 * 2, load_half = (half + 255) / 256;
+    if (tile == 32 || (tile == 0 && small > 256 && 5 * load_half <= 4 * load_small))
+      return launch_gemm<32, 64, LAYOUT, VEC, 4>(a, stream);
+  } else if (tile == 32) {
+    return DTF_ERR_UNSUPPORTED;
+  }
+  return launch_gemm<64, 64, LAYOUT, VEC, 8>(a, stream);
 }
 
 // ---- column sums: out[n] (op)= scale * sum_m z[m][n] -------------------------------------------------------------
@@ -808,7 +834,7 @@ extern "C" int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float*
   if ((layout == DTF_GEMM_TN ? lda < M : lda < K) || (layout == DTF_GEMM_NT ? ldb < K : ldb < N)) return DTF_ERR_SHAPE;
   if (epi == DTF_EPI_ACT_BWD && (aux == nullptr || ldaux < N)) return DTF_ERR_NULL;
   if (epi == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
-  if (tile != 0 && tile != 64 && tile != 128) return DTF_ERR_SHAPE;
+  if (tile != 0 && tile != 32 && tile != 64 && tile != 128) return DTF_ERR_SHAPE;
   // byte offsets inside a tile (k along memory: 128 rows; k strided: the 32 rows of a chunk) are 32-bit
   if ((128 * lda + K) * 4 >= (1LL << 31) || (128 * ldb + K) * 4 >= (1LL << 31)) return DTF_ERR_UNSUPPORTED;
   GemmArgs a{};
