@@ -48,9 +48,14 @@ def main():
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     common = [f"--epochs={a.epochs}", f"--transport={a.transport}", "--logs_path=/tmp/dtf_bench_logs", *a.extra]
     procs = []
+    import tempfile
+
+    times_dir = tempfile.mkdtemp(prefix="dtf_epoch_times_")
     for job, n in (("ps", a.ps), ("worker", a.workers)):
         for i in range(n):
             cmd = [sys.executable, "-u", os.path.join(ROOT, a.script), f"--job_name={job}", f"--task_index={i}", *common]
+            if job == "worker":       # the loop's own epoch times as floats (stdout rounds them to 10 ms)
+                env = dict(env, DTF_EPOCH_TIMES_FILE=os.path.join(times_dir, f"worker{i}.json"))
             procs.append((f"{job}{i}", subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                                         stderr=subprocess.STDOUT, text=True)))
     t0 = time.time()
@@ -67,6 +72,12 @@ def main():
         rc = rc or p.returncode
         if name.startswith("worker"):
             times = [float(x) for x in re.findall(r"Total Time: ([\d.]+)s", out)]
+            try:
+                with open(os.path.join(times_dir, name + ".json")) as f:
+                    exact = [float(t) for t in json.load(f)["epoch_times"]]
+                times = exact if len(exact) == len(times) else times
+            except (OSError, ValueError, KeyError):
+                pass
             accs = [float(x) for x in re.findall(r"Test-Accuracy: ([\d.]+)", out)]
             steps = [int(x) for x in re.findall(r"Step: (\d+),", out)]
             result["tasks"][name] = {

@@ -9,6 +9,7 @@ attribute access (the reference never calls ``tf.app.run()``), accepting both
 """
 from __future__ import annotations
 
+import os
 import sys
 from typing import Any, Callable, Dict, List, Optional
 
@@ -156,4 +157,27 @@ def run(main=None, argv=None):
     """``tf.app.run``: parse flags, call ``main(argv)`` and exit with its return value."""
     FLAGS._parse(argv[1:] if argv else None)
     main = main or sys.modules["__main__"].main
-    sys.exit(main([sys.argv[0]] + FLAGS.unparsed))
+    prof_dir = os.environ.get("DTF_CPROFILE_DIR")
+    if not prof_dir:
+        sys.exit(main([sys.argv[0]] + FLAGS.unparsed))
+    # DTF_CPROFILE_DIR=<dir>: the task runs under cProfile and leaves <dir>/<script>_<job>_<task>.txt (functions by
+    # own time and by cumulative time) -- where the host time of a per-batch tier goes, per task of a cluster
+    import cProfile
+    import io
+    import pstats
+
+    pr = cProfile.Profile()
+    rc = 0
+    try:
+        rc = pr.runcall(main, [sys.argv[0]] + FLAGS.unparsed)
+    finally:
+        os.makedirs(prof_dir, exist_ok=True)
+        tag = "_".join(str(v) for v in (os.path.basename(sys.argv[0]).replace(".py", ""),
+                                        getattr(FLAGS, "job_name", "") or "local", getattr(FLAGS, "task_index", 0)))
+        buf = io.StringIO()
+        st = pstats.Stats(pr, stream=buf)
+        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("cumtime").print_stats(r"distributed_tensorflow_amd|tfdist|tfsingle", 60)
+        with open(os.path.join(prof_dir, tag + ".txt"), "w") as f:
+            f.write(buf.getvalue())
+    sys.exit(rc)

@@ -43,6 +43,7 @@ tokens, locks) uses the native task servers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import struct
 import time
 from typing import List, Optional
@@ -502,10 +503,76 @@ class IpcVariableStore:
     def take_apply_release(self, clients, num_required: int, lr: float, tokens: int, timeout: float) -> int:
         """Chief aggregator, a whole round: arrivals (one request), the update (one launch per shard), tokens (one
         request).  A TimeoutError leaves the round open."""
+        done = self._native_round(num_required, lr, tokens, timeout)
+        if done is not None:
+            return done
         step = self.take_apply_all(clients, num_required, lr, timeout)
         with span("release_tokens"):
             self.enqueue_tokens(clients, step, tokens)
         return step
+
+    def _native_round(self, num_required: int, lr: float, tokens: int, timeout: float) -> Optional[int]:
+        """The common round -- every worker arrives, in step, with the same mailbox row -- as ONE native call
+        (``dtf_sync_round``: arrivals, one ``dtf_sum_apply`` per shard, the wait for them, the tokens): the replicas wait
+        for exactly this stretch, and the interpreter's share of it (context managers, ctypes calls, the lock of a thread
+        that shares its interpreter with the chief's own training loop) was most of it.  Returns the new step, or None
+        with whatever arrived moved into ``_arrived`` for the general path (DTF_SYNC_NATIVE_ROUND=0: never used)."""
+        board = self._get_board()
+        per_worker = spread_tokens(tokens, self.n_workers)
+        if (board is None or self._arrived or num_required != self.n_workers or self.n_workers > 16
+                or per_worker[0] <= 0 or len(set(per_worker)) != 1
+                or os.environ.get("DTF_SYNC_NATIVE_ROUND", "1") == "0"):
+            return None
+        plan = getattr(self, "_round_plan", None)
+        if plan is None:
+            shards = [k for k in range(self.n) if self.layout.shard_numel(k)]
+            params = [self._params(k) for k in shards]
+            tabs = [(C.c_uint64 * self.n_workers)(*[self._mailbox(k, w, slot).data_ptr() for w in range(self.n_workers)])
+                    for slot in (0, 1) for k in shards]
+            gs = [p[self._gs_off:self._gs_off + 1].data_ptr() if k == self._gs_shard else None
+                  for k, p in zip(shards, params)]
+            plan = self._round_plan = {
+                "n": len(shards), "keep": (params, tabs),
+                "params": (C.c_void_p * len(shards))(*[p.data_ptr() for p in params]),
+                "tabs": (C.c_void_p * len(tabs))(*[C.cast(t, C.c_void_p).value for t in tabs]),
+                "numel": (C.c_int64 * len(shards))(*[p.numel() for p in params]),
+                "gs": (C.c_void_p * len(shards))(*gs),
+                "out": (C.c_int64 * (3 * 16))(), "got": C.c_int(0), "entry": board.native_entry_points(),
+            }
+            self._agg_stream = getattr(self, "_agg_stream", None) or torch.cuda.Stream(device=self.device)
+            if getattr(self, "_agg_lr", None) is None:
+                self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+                self._agg_lr_val = None
+            lib = hb.require()
+            lib.dtf_sync_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.dtf_sync_round.restype = C.c_int
+        if self._agg_lr_val != lr:
+            with torch.cuda.stream(self._agg_stream):
+                self._agg_lr.fill_(float(lr))
+            self._agg_lr_val = lr
+        take, release, handle = plan["entry"]
+        with span("native_round"), torch.cuda.device(self.device):
+            rc = hb.require().dtf_sync_round(take, release, handle, self.n_workers, self._acc_step,
+                                            max(0, int(timeout * 1000)), plan["n"], plan["params"], plan["tabs"],
+                                            plan["numel"], plan["gs"], self._agg_lr.data_ptr(), per_worker[0],
+                                            self._agg_stream.cuda_stream, plan["out"], C.byref(plan["got"]))
+        if rc == 0:
+            self._acc_step += 1
+            return self._acc_step
+        if rc not in (1, 2):
+            hb._check(rc, "dtf_sync_round")
+        out = plan["out"]
+        for i in range(plan["got"].value):      # the general path's bookkeeping for what was taken
+            w, step, slot = out[3 * i], out[3 * i + 1], out[3 * i + 2]
+            if step < self._acc_step:
+                self.dropped += 1
+            elif all(w != a for a, _ in self._arrived):
+                self._arrived.append((int(w), int(slot)))
+        if rc == 2 and len(self._arrived) < num_required:
+            raise TimeoutError("sync aggregation: not enough fresh gradients yet")
+        return None
 
     def enqueue_tokens(self, clients, step: int, n: int):
         per_worker = spread_tokens(n, self.n_workers)

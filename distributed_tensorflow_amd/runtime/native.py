@@ -433,6 +433,12 @@ class Board:
     def attached(self) -> int:
         return int(lib().dtf_board_attached(self._h))
 
+    def native_entry_points(self):
+        """(address of dtf_board_take, address of dtf_board_release, the board's handle): for code in another library
+        that runs a whole round of the chief without the interpreter (``dtf_sync_round`` of the kernel library)."""
+        l = lib()
+        return (C.cast(l.dtf_board_take, C.c_void_p).value, C.cast(l.dtf_board_release, C.c_void_p).value, self._h)
+
     def close(self):
         if self._h:
             lib().dtf_board_close(self._h)
