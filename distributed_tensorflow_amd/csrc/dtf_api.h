@@ -106,11 +106,12 @@ int dtf_sgd_apply_atomic(float* p, const float* g, int64_t n, const float* lr, f
 // grads: HOST array of `count` <= 16 device addresses.
 int dtf_sum_apply(float* p, const uint64_t* grads, int count, int64_t n, const float* lr, float scale,
                   float* global_step, void* stream);
-// A whole round of the chief of synchronous replicas on the shared-memory board (arrivals, dtf_sum_apply per shard,
-// wait, tokens) when the arrivals are one per worker, of step round_step and of one mailbox row; see optim.hip.
-int dtf_sync_round(void* take_fn, void* release_fn, void* board, int workers, int64_t round_step, int timeout_ms,
-                   int n_shards, float* const* params, const uint64_t* const* tabs, const int64_t* numel,
-                   float* const* global_step, const float* lr, int copies, void* stream, int64_t* out, int* got);
+// Whole rounds of the chief of synchronous replicas on the shared-memory board (arrivals, dtf_sum_apply per shard, wait,
+// tokens) for as long as the arrivals are one per worker, in step and of one mailbox row; see optim.hip.
+int dtf_sync_rounds(void* take_fn, void* release_fn, void* board, int workers, int64_t round_step, int timeout_ms,
+                    int n_shards, float* const* params, const uint64_t* const* tabs, const int64_t* numel,
+                    float* const* global_step, const float* lr, int copies, void* stream, int max_rounds, int64_t* out,
+                    int* got, int* rounds);
 // acc[i] += g[i]
 int dtf_accumulate(float* acc, const float* g, int64_t n, void* stream);
 // Philox4x32-10 + Box-Muller normal fill: out[i] = mean + std * N(0,1), a pure

@@ -242,50 +242,57 @@ extern "C" int dtf_sum_apply(float* p, const uint64_t* grads, int count, int64_t
   return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
 }
 
-// One round of the chief of synchronous replicas whose barrier is the shared-memory board (runtime/shm_board.cpp), on
-// its common path, without a line of interpreter in between: take the arrivals of all `workers`, and if they are what a
-// round in step looks like -- one per worker, all of step `round_step`, all in the same mailbox row `slot` -- apply the
-// mean of that row's gradients to every shard (dtf_sum_apply, one launch per shard, worker order), wait for the
-// launches and deal `copies` tokens of step round_step + 1 to every worker (tfdist_between_sync.py:65-68, 86-89).
-// take / release are dtf_board_take / dtf_board_release, handed over as addresses (they live in the runtime library).
-// shards: n_shards entries; tabs[slot * n_shards + k]: HOST array of `workers` device addresses (the mailbox rows).
-// Returns DTF_OK (round applied), 1 (arrivals that are not such a round: they are in out[0 .. 3 * *got), nothing was
-// applied, the caller goes on with them) or 2 (time-out: *got arrivals taken so far are in out).
-extern "C" int dtf_sync_round(void* take_fn, void* release_fn, void* board, int workers, int64_t round_step, int timeout_ms,
-                              int n_shards, float* const* params, const uint64_t* const* tabs, const int64_t* numel,
-                              float* const* global_step, const float* lr, int copies, void* stream, int64_t* out,
-                              int* got) {
+// Rounds of the chief of synchronous replicas whose barrier is the shared-memory board (runtime/shm_board.cpp), on their
+// common path, without a line of interpreter in between (the chief's thread shares an interpreter, and its lock, with the
+// training loop of the chief's own replica): take the arrivals of all `workers`, and if they are what a round in step
+// looks like -- one per worker, all of step `round_step`, all in the same mailbox row `slot` -- apply the mean of that
+// row's gradients to every shard (dtf_sum_apply, one launch per shard, worker order), wait for the launches and deal
+// `copies` tokens of step round_step + 1 to every worker (tfdist_between_sync.py:65-68, 86-89); then the next round,
+// up to max_rounds of them.  take / release are dtf_board_take / dtf_board_release, handed over as addresses (they live
+// in the runtime library).  shards: n_shards entries; tabs[slot * n_shards + k]: HOST array of `workers` device
+// addresses (the mailbox rows).  *rounds: rounds applied.  Returns DTF_OK (max_rounds applied), 1 (arrivals that are
+// not such a round: they are in out[0 .. 3 * *got), not applied, the caller goes on with them) or 2 (time-out of a
+// round: the *got arrivals taken for it are in out).
+extern "C" int dtf_sync_rounds(void* take_fn, void* release_fn, void* board, int workers, int64_t round_step, int timeout_ms,
+                               int n_shards, float* const* params, const uint64_t* const* tabs, const int64_t* numel,
+                               float* const* global_step, const float* lr, int copies, void* stream, int max_rounds,
+                               int64_t* out, int* got, int* rounds) {
   typedef int (*TakeFn)(void*, int, int, int64_t*, int*);
   typedef int (*ReleaseFn)(void*, int64_t, int64_t, int);
-  if (!take_fn || !release_fn || !board || !params || !tabs || !numel || !global_step || !lr || !out || !got)
+  if (!take_fn || !release_fn || !board || !params || !tabs || !numel || !global_step || !lr || !out || !got || !rounds)
     return DTF_ERR_NULL;
   if (workers < 1 || workers > kMaxSources || n_shards < 1) return DTF_ERR_SHAPE;
-  *got = 0;
-  int n = 0;
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
-  while (n < workers) {       // (a take returns with the arrivals there are once there is one)
-    const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
-    int g = 0;
-    const int rc = reinterpret_cast<TakeFn>(take_fn)(board, workers - n, left > 0 ? (int)left : 0, out + 3 * n, &g);
-    n += g > 0 ? g : 0;
-    *got = n;
-    if (rc != 0 && n < workers) return 2;
+  *rounds = 0;
+  for (int r = 0; r < max_rounds; ++r, ++round_step) {
+    *got = 0;
+    int n = 0;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    while (n < workers) {       // (a take returns with the arrivals there are once there is one)
+      const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+      int g = 0;
+      const int rc = reinterpret_cast<TakeFn>(take_fn)(board, workers - n, left > 0 ? (int)left : 0, out + 3 * n, &g);
+      n += g > 0 ? g : 0;
+      *got = n;
+      if (rc != 0 && n < workers) return 2;
+    }
+    unsigned seen = 0;
+    const int64_t slot = out[2];
+    for (int i = 0; i < n; ++i) {
+      const int64_t w = out[3 * i], step = out[3 * i + 1];
+      if (w < 0 || w >= workers || step != round_step || out[3 * i + 2] != slot || (seen >> w & 1u)) return 1;
+      seen |= 1u << w;
+    }
+    if (slot < 0 || slot > 1) return 1;
+    for (int k = 0; k < n_shards; ++k) {
+      const int e = dtf_sum_apply(params[k], tabs[slot * n_shards + k], workers, numel[k], lr, 1.0f / (float)workers,
+                                  global_step[k], stream);
+      if (e != DTF_OK) return e;
+    }
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DTF_ERR_LAUNCH;   // tokens must not overtake the update
+    *got = 0;
+    if (reinterpret_cast<ReleaseFn>(release_fn)(board, -1, round_step + 1, copies) != 0) return DTF_ERR_LAUNCH;
+    *rounds = r + 1;
   }
-  unsigned seen = 0;
-  const int64_t slot = out[2];
-  for (int i = 0; i < n; ++i) {
-    const int64_t w = out[3 * i], step = out[3 * i + 1];
-    if (w < 0 || w >= workers || step != round_step || out[3 * i + 2] != slot || (seen >> w & 1u)) return 1;
-    seen |= 1u << w;
-  }
-  if (slot < 0 || slot > 1) return 1;
-  for (int k = 0; k < n_shards; ++k) {
-    const int e = dtf_sum_apply(params[k], tabs[slot * n_shards + k], workers, numel[k], lr, 1.0f / (float)workers,
-                                global_step[k], stream);
-    if (e != DTF_OK) return e;
-  }
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return DTF_ERR_LAUNCH;     // tokens must not overtake the update
-  if (reinterpret_cast<ReleaseFn>(release_fn)(board, -1, round_step + 1, copies) != 0) return DTF_ERR_LAUNCH;
   return DTF_OK;
 }
 

@@ -124,7 +124,7 @@ class QueueRunner:
                         # to the shard that keeps global_step (tfdist_between_sync.py:65-68, 86-89)
                         with span("aggregate_apply_release", required=required):
                             store.take_apply_release(clients, required, opt.lr_value(), opt.tokens_per_step, timeout=0.5)
-                        self.rounds += 1
+                        self.rounds += getattr(store, "rounds_in_last_call", 1)     # (a native call may apply several)
                         idle_since = None
                         continue
                     with span("aggregate_apply", required=required):

@@ -509,14 +509,22 @@ class IpcVariableStore:
         step = self.take_apply_all(clients, num_required, lr, timeout)
         with span("release_tokens"):
             self.enqueue_tokens(clients, step, tokens)
+        self.rounds_in_last_call = 1 + getattr(self, "_carry_rounds", 0)
+        self._carry_rounds = 0
         return step
 
+    #: rounds that one native call may apply before the interpreter looks at the learning rate and at the coordinator again
+    NATIVE_ROUNDS_PER_CALL = 32
+
     def _native_round(self, num_required: int, lr: float, tokens: int, timeout: float) -> Optional[int]:
-        """The common round -- every worker arrives, in step, with the same mailbox row -- as ONE native call
-        (``dtf_sync_round``: arrivals, one ``dtf_sum_apply`` per shard, the wait for them, the tokens): the replicas wait
-        for exactly this stretch, and the interpreter's share of it (context managers, ctypes calls, the lock of a thread
-        that shares its interpreter with the chief's own training loop) was most of it.  Returns the new step, or None
-        with whatever arrived moved into ``_arrived`` for the general path (DTF_SYNC_NATIVE_ROUND=0: never used)."""
+        """The common rounds -- every worker arrives, in step, with the same mailbox row -- inside ONE native call
+        (``dtf_sync_rounds``: arrivals, one ``dtf_sum_apply`` per shard, the wait for them, the tokens, and the same again
+        for up to NATIVE_ROUNDS_PER_CALL rounds): the replicas wait for exactly this stretch, and the interpreter's share
+        of it (context managers, ctypes calls, and above all the lock that the chief's thread shares with the training
+        loop of the chief's own replica, which fell 50 - 70 us behind the other replicas every round) was most of it.
+        Returns the new step, or None with whatever arrived moved into ``_arrived`` for the general path
+        (DTF_SYNC_NATIVE_ROUND=0: never used).  ``rounds_in_last_call`` says how many rounds the call applied."""
+        self.rounds_in_last_call = 1
         board = self._get_board()
         per_worker = spread_tokens(tokens, self.n_workers)
         if (board is None or self._arrived or num_required != self.n_workers or self.n_workers > 16
@@ -537,39 +545,45 @@ class IpcVariableStore:
                 "tabs": (C.c_void_p * len(tabs))(*[C.cast(t, C.c_void_p).value for t in tabs]),
                 "numel": (C.c_int64 * len(shards))(*[p.numel() for p in params]),
                 "gs": (C.c_void_p * len(shards))(*gs),
-                "out": (C.c_int64 * (3 * 16))(), "got": C.c_int(0), "entry": board.native_entry_points(),
+                "out": (C.c_int64 * (3 * 16))(), "got": C.c_int(0), "rounds": C.c_int(0),
+                "entry": board.native_entry_points(),
             }
             self._agg_stream = getattr(self, "_agg_stream", None) or torch.cuda.Stream(device=self.device)
             if getattr(self, "_agg_lr", None) is None:
                 self._agg_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
                 self._agg_lr_val = None
             lib = hb.require()
-            lib.dtf_sync_round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                           C.c_void_p, C.c_void_p, C.c_void_p]
-            lib.dtf_sync_round.restype = C.c_int
+            lib.dtf_sync_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.dtf_sync_rounds.restype = C.c_int
         if self._agg_lr_val != lr:
             with torch.cuda.stream(self._agg_stream):
                 self._agg_lr.fill_(float(lr))
+            self._agg_stream.synchronize()
             self._agg_lr_val = lr
         take, release, handle = plan["entry"]
-        with span("native_round"), torch.cuda.device(self.device):
-            rc = hb.require().dtf_sync_round(take, release, handle, self.n_workers, self._acc_step,
-                                            max(0, int(timeout * 1000)), plan["n"], plan["params"], plan["tabs"],
-                                            plan["numel"], plan["gs"], self._agg_lr.data_ptr(), per_worker[0],
-                                            self._agg_stream.cuda_stream, plan["out"], C.byref(plan["got"]))
-        if rc == 0:
-            self._acc_step += 1
-            return self._acc_step
-        if rc not in (1, 2):
-            hb._check(rc, "dtf_sync_round")
+        with span("native_rounds"), torch.cuda.device(self.device):
+            rc = hb.require().dtf_sync_rounds(take, release, handle, self.n_workers, self._acc_step,
+                                             max(0, int(timeout * 1000)), plan["n"], plan["params"], plan["tabs"],
+                                             plan["numel"], plan["gs"], self._agg_lr.data_ptr(), per_worker[0],
+                                             self._agg_stream.cuda_stream, self.NATIVE_ROUNDS_PER_CALL, plan["out"],
+                                             C.byref(plan["got"]), C.byref(plan["rounds"]))
+        done = plan["rounds"].value
+        self._acc_step += done
+        if rc not in (0, 1, 2):
+            hb._check(rc, "dtf_sync_rounds")
         out = plan["out"]
-        for i in range(plan["got"].value):      # the general path's bookkeeping for what was taken
+        for i in range(plan["got"].value if rc != 0 else 0):      # the general path's bookkeeping for what was taken
             w, step, slot = out[3 * i], out[3 * i + 1], out[3 * i + 2]
             if step < self._acc_step:
                 self.dropped += 1
             elif all(w != a for a, _ in self._arrived):
                 self._arrived.append((int(w), int(slot)))
+        if done > 0 and (rc == 0 or not self._arrived or rc == 2):
+            self.rounds_in_last_call = done
+            return self._acc_step
+        self._carry_rounds = getattr(self, "_carry_rounds", 0) + done      # counted when the general path ends its round
         if rc == 2 and len(self._arrived) < num_required:
             raise TimeoutError("sync aggregation: not enough fresh gradients yet")
         return None
