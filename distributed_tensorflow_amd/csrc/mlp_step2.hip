@@ -293,7 +293,9 @@ __device__ __forceinline__ void fwd_tile8_body(
     return;
   }
   DTF_BLOCK_STAMP(bs, 0);
-  __shared__ float red[kFwd8Waves][4][64];
+  // rows of 72 floats: the reduction below reads (4 registers) x (8 columns) per 32 lanes, and with 64-float rows the four
+  // registers met in the same 8 banks (4-way conflicts on all 16 reads: 38,000 conflict cycles per launch)
+  __shared__ float red[kFwd8Waves][4][72];
   __shared__ float psum[2][64];
   __shared__ float a2t[8][9];
   __shared__ float w2t[64][17];   // rows >= 8 are written (never read) so that the W2 load is used by every thread

@@ -689,7 +689,7 @@ class Session:
                 else:
                     eng.step_grad(0, 1.0)
             with span("fetch_stats"):
-                host = torch.stack((eng.loss_sum[0], eng.correct[0].to(torch.float32))).cpu() / float(eng.B)
+                host = self._stats_to_host(torch.stack((eng.loss_sum[0], eng.correct[0].to(torch.float32)))) / float(eng.B)
             cache[d["loss"]] = host[0]
             cache[("acc", id(d["loss"]))] = host[1]
             for n in plan["acc_nodes"]:
