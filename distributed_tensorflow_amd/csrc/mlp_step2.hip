@@ -276,8 +276,32 @@ __device__ __forceinline__ void fwd_tile8_body(
   // clears the other logit accumulator, beside the tiles instead of at the tail of one of them.
   // For the cross-replica backward of the SAME step it also numbers the exchange: one writer, in a launch
   // of its own, so every workgroup of the backward launch reads the same number without any atomic.
-  if (blockIdx.y == gridDim.y - 1) {
-    if (blockIdx.x == 0) {
+  // Which tile: block (x, y) = tile (tn, tm).  Workgroups go to the 8 XCDs round-robin, each XCD with an L2 of its own,
+  // so every XCD meets every row of the batch and every column of W1 and fetches both whole (8 x 0.63 MB per launch,
+  // 42,500 L2 misses).  -DDTF_FWD8_XCD=1 gives XCD c the c-th run of a tile order that walks strips of three tile
+  // columns row by row (~7 tile rows x 3 tile columns per XCD): the misses halve (20,200) and the kernel gets SLOWER,
+  // 4.5 -> 5.0 us in a kernel trace and 11.4 -> 14.5 us per two-launch step: a tile waits for a cold stream of 50 KB,
+  // and 22 tiles that ask one L2 for the same lines at the same moment wait longer than 22 tiles that ask eight.
+#ifndef DTF_FWD8_XCD
+#define DTF_FWD8_XCD 0
+#endif
+  const int tiles_n = gridDim.x, tiles_m = gridDim.y - 1;
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool remap = DTF_FWD8_XCD && tiles_n >= 8;
+  int tn = blockIdx.x, tm = blockIdx.y;
+  bool duty = blockIdx.y == gridDim.y - 1 && blockIdx.x == 0;
+  if (remap) {
+    const int ntiles = tiles_m * tiles_n, per = (ntiles + 7) >> 3;
+    duty = lin == (int)(gridDim.x * gridDim.y) - 1;
+    const int t = (lin & 7) * per + (lin >> 3);
+    if (!duty && (lin >= 8 * per || t >= ntiles)) return;
+    const int ns = tiles_n / 3, strip = min(t / (3 * tiles_m), ns - 1), base = strip * 3 * tiles_m;
+    const int width = strip == ns - 1 ? tiles_n - 3 * (ns - 1) : 3;
+    tm = (t - base) / width;
+    tn = 3 * strip + (t - base) - tm * width;
+  }
+  if (duty || (!remap && blockIdx.y == gridDim.y - 1)) {
+    if (duty) {
       if (exchange_counter && threadIdx.x == 0) *exchange_counter += 1u;
       const int hcw = H * C;
       if (shadow_dst) {
@@ -302,7 +326,6 @@ __device__ __forceinline__ void fwd_tile8_body(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, q = lane >> 4;
   const int r8 = i16 & 7, g = i16 >> 3;
-  const int tn = blockIdx.x, tm = blockIdx.y;
   const int m0 = tm * 8, n0 = tn * 8;
   const float* __restrict__ X = xbase + batch_index * (long)M * (long)K;
   const int row = m0 + r8, col = n0 + r8;
