@@ -85,3 +85,35 @@ def test_launches_of_a_set_go_to_its_own_device_whatever_device_is_current(monke
     with ds._on_device():
         pass
     assert seen == [torch.device("cuda", 3)]
+
+
+def test_next_batch_orders_are_those_of_a_fresh_images_perm_per_epoch():
+    """The reshuffle is drawn one epoch ahead and gathered on a background thread into a second pair of arrays
+    (data/mnist.py::DataSet._shuffle); the batches are those of ``images = images[perm]`` at every epoch boundary with
+    the same generator (mnist.train.next_batch, tfdist_between.py:92), also when a batch straddles the boundary."""
+    import numpy as np
+
+    from distributed_tensorflow_amd.data.mnist import DataSet
+
+    rng = np.random.RandomState(0)
+    x = rng.rand(5000, 24).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 5000)]
+    for n, batch in ((5000, 100), (1050, 100)):
+        a = DataSet(x[:n].copy(), y[:n].copy(), seed=3)
+        r = np.random.RandomState(3)
+        xi, yi = x[:n].copy(), y[:n].copy()
+        perm = r.permutation(n)
+        xi, yi = xi[perm], yi[perm]
+        pos = 0
+        for _ in range(3 * n // batch + 5):
+            bx, by = a.next_batch(batch)
+            if pos + batch > n:
+                rest_x, rest_y = xi[pos:], yi[pos:]
+                perm = r.permutation(n)
+                xi, yi = xi[perm], yi[perm]
+                pos = batch - len(rest_x)
+                want_x, want_y = np.concatenate((rest_x, xi[:pos])), np.concatenate((rest_y, yi[:pos]))
+            else:
+                want_x, want_y = xi[pos:pos + batch], yi[pos:pos + batch]
+                pos += batch
+            assert np.array_equal(bx, want_x) and np.array_equal(by, want_y)

@@ -86,17 +86,19 @@ def test_rccl_world_of_one_with_graph_capture(mode):
 @pytest.mark.parametrize("script,n_ps,n_w,board", [("tfdist_between.py", 1, 1, "1"), ("tfdist_between.py", 2, 2, "1"),
                                                    ("tfdist_between_sync.py", 1, 2, "1"),
                                                    ("tfdist_between_sync.py", 2, 3, "1"),
-                                                   ("tfdist_between_sync.py", 1, 2, "0")])
+                                                   ("tfdist_between_sync.py", 1, 2, "0"),
+                                                   ("tfdist_between_sync.py", 1, 2, "1-interpreter")])
 def test_ipc_transport_gpu_resident_shards(script, n_ps, n_w, board, tmp_path):
     """PS and workers as separate processes sharing the GPU; shards live in the PS task's HBM (HIP-IPC).  The
-    synchronous barrier runs over the shared-memory board of the node (board "1") or over the task server's sockets."""
+    synchronous barrier runs over the shared-memory board of the node (board "1": the chief's common rounds as native
+    code, ``dtf_sync_rounds``; "1-interpreter": every round in the interpreter) or over the task server's sockets."""
     import re
 
     from cluster_utils import launch_script
 
     args = ["--epochs=1", "--train_size=1100", "--freq=5", "--lr=0.01", "--nosummaries", "--transport=ipc",
             f"--logs_path={tmp_path}"]
-    res = launch_script(script, n_ps, n_w, args, timeout=200, env_extra={"DTF_SYNC_BOARD": board})
+    res = launch_script(script, n_ps, n_w, args, timeout=200, env_extra={"DTF_SYNC_BOARD": board[0], "DTF_SYNC_NATIVE_ROUND": "0" if board.endswith("interpreter") else "1"})
     for name, (rc, out) in res.items():
         assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
     assert "resident on cuda" in res["ps0"][1]
