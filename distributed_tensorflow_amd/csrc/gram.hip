@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
   const unsigned src_bytes = (unsigned)a.rows_src * rowbytes, dst_bytes = a.dst != nullptr ? (unsigned)(a.nb * B) * rowbytes : 0u;
   const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), (short)0, (int)src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.dst, (short)0, (int)((a.parts & 4) ? dst_bytes : 0u), 0x00020000);
-  constexpr unsigned kBeyond = 0xffffffffu;
+  constexpr unsigned kBeyond = 0xfffffff0u;                   // (+ 12 for the last of four dwords does not wrap)
   unsigned srcoff[kPLoads];                                   // byte offset of the source row; kBeyond: no load
   int ldsoff[kPLoads];                                        // wave-uniform: the group's first row in img, in units of 16 floats
   unsigned dstrow[kPLoads];                                   // wave-uniform: epoch row of the group's first row
@@ -278,8 +278,8 @@ extern "C" int dtf_gather_gram(const float* src, const int64_t* perm, float* dst
   if (!dtf_gather_gram_supported(B, K) || nb < 2 || ld < B || ld > kRowsB || (ld & 15) || rows_src < 1)
     return DTF_ERR_SHAPE;
   if (!aligned16(src) || (dst && !aligned16(dst)) || !aligned16(gram)) return DTF_ERR_SHAPE;
-  // byte offsets are 32-bit, and 0xffffffff means "no access": a row's offset plus an offset inside a row must stay below it
-  if (((long)rows_src + 1) * K * 4 >= (1L << 32) - 1 || ((long)nb * B + 1) * K * 4 >= (1L << 32) - 1) return DTF_ERR_SHAPE;
+  // byte offsets are 32-bit, and 0xfffffff0 means "no access": a row's offset plus an offset inside a row must stay below it
+  if (((long)rows_src + 1) * K * 4 >= 0xfffffff0L || ((long)nb * B + 1) * K * 4 >= 0xfffffff0L) return DTF_ERR_SHAPE;
   if ((ysrc == nullptr) != (ydst == nullptr) || (ydst && C < 1)) return DTF_ERR_NULL;
   GramArgs a{src, perm, dst, gram, B, K, nb, ld, rows_src, ysrc, ydst, C, g_gram_parts, g_gram_stamps};
   // a workgroup's units: at most 16 (one per wave), and few enough that its batches' row groups fit 8 loads a thread

@@ -410,7 +410,7 @@ class DeviceDataset:
         from ..ops import hip_backend as hb
 
         return (hb.gather_gram_supported(self.batch_size, self.x.shape[1])
-                and self.num_examples * self.x.shape[1] * 4 < 2 ** 32)
+                and (self.num_examples + 1) * self.x.shape[1] * 4 < 0xfffffff0)      # 32-bit byte offsets in the kernel
 
     def _alloc_gram(self, s):
         nb, b = self.batches_per_epoch, self.batch_size
