@@ -309,6 +309,46 @@ def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float =
     return {"error": f"{note}: {text[-300:]}"}
 
 
+def _child_clusters(use_cpu: bool, limit_s: float = 60.0) -> dict:
+    """The reference's between-graph recipes as it runs them (README.md:88-113, 150-176 there): the repository's
+    ``tfdist_between.py`` / ``tfdist_between_sync.py`` as one process per task -- asynchronous 1 ps + 1 worker and
+    1 ps + 2 workers, synchronous 1 ps + 2 workers -- with all tasks on this GPU and the shards in the ps task's HBM
+    (``--transport=ipc``; on the CPU, where the stage only runs when DTF_BENCH_CLUSTERS=1 asks for it: tcp and 1,100
+    training rows).  Reports the slowest worker's mean time of
+    the epochs after the first, from the scripts' own epoch clocks."""
+    from .utils.local_cluster import run_local_cluster
+
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k)
+    extra = []
+    if use_cpu:
+        env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+        extra = ["--train_size=1100"]
+    out = {"what": "the scripts as separate tasks (one process each, all on this GPU), one sess.run per batch, "
+                   + ("tcp shards on the host" if use_cpu else "shards in the ps task's HBM (HIP-IPC)")
+                   + "; the slowest worker's mean epoch after the first"}
+    for key, script, n_ps, n_w in (("async_1ps_1w", "tfdist_between.py", 1, 1), ("async_1ps_2w", "tfdist_between.py", 1, 2),
+                                   ("sync_1ps_2w", "tfdist_between_sync.py", 1, 2)):
+        try:
+            r = run_local_cluster(script, n_ps, n_w, "tcp" if use_cpu else "ipc", epochs=4, extra=extra, timeout=limit_s,
+                                  env=env)
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        workers = [t for name, t in r["tasks"].items() if name.startswith("worker")]
+        steady = [t.get("steady_epoch_s") for t in workers]
+        if r["returncode"] != 0 or not steady or any(v is None for v in steady):
+            out[key] = {"error": "the cluster did not finish", "tasks": {k: {kk: vv for kk, vv in t.items() if kk != "epoch_times"}
+                                                                       for k, t in r["tasks"].items()}}
+            continue
+        out[key] = {"sec_per_epoch": round(max(steady), 5), "workers": n_w, "ps": n_ps,
+                    "last_step": [t.get("last_step") for t in workers],
+                    "final_accuracy": [t.get("final_accuracy") for t in workers]}
+    return out
+
+
 def _child_per_batch_epoch(use_cpu: bool, limit_s: float = 90.0) -> dict:
     """The reference's LITERAL epoch (tfsingle.py:72-97): 550 x {next_batch, ``sess.run([train_op, cost, summary,
     global_step], feed_dict)``, ``add_summary``} + the full test-set evaluation, timed by the script itself as
@@ -808,6 +848,19 @@ def run_benchmark(args) -> Optional[dict]:
         result_extra["per_batch_tier"] = rep
         if "sec_per_epoch" in rep:
             result_extra["sec_per_epoch_per_batch_tier"] = rep["sec_per_epoch"]
+
+    # ---- the reference's PS / worker recipes in their literal form: the scripts as separate tasks, one sess.run per batch
+    if (n == 1 and not ingraph_only and args.mode in (None, "auto", "single")
+            and os.environ.get("DTF_BENCH_CLUSTERS", "0" if use_cpu else "1") != "0" and within_budget()):
+        wd.stage("per-batch PS/worker clusters (child processes)", limit_s=200.0)
+        try:
+            rep = _child_clusters(use_cpu)
+        except Exception as e:  # noqa: BLE001 — an extra measurement must never cost the headline one
+            rep = {"error": f"{type(e).__name__}: {e}"}
+        result_extra["per_batch_clusters"] = rep
+        for key, v in rep.items():
+            if isinstance(v, dict) and "sec_per_epoch" in v:
+                result_extra[f"sec_per_epoch_{key}_per_batch"] = v["sec_per_epoch"]
 
     result = None
     if rank == 0:
