@@ -141,7 +141,7 @@ class _Reorder:
         def work():
             try:
                 for src, dst in zip(srcs, dsts):
-                    np.take(src, order, axis=0, out=dst)
+                    np.take(src, order, axis=0, out=dst, mode="clip")     # ("raise" gathers into a temporary first)
             except BaseException as e:  # noqa: BLE001 - handed to the thread that asks for the result
                 self.error = e
 
@@ -214,7 +214,8 @@ class DataSet:
         if start + batch_size > self._num_examples:
             self._epochs_completed += 1
             rest = self._num_examples - start
-            img_rest, lab_rest = self._images[start:], self._labels[start:]
+            # (copies: the reshuffle hands these arrays to the background gather of the order after the next)
+            img_rest, lab_rest = self._images[start:].copy(), self._labels[start:].copy()
             if shuffle:
                 self._shuffle()
             self._index_in_epoch = batch_size - rest

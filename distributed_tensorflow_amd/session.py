@@ -223,10 +223,10 @@ class Session:
         # Pinned host words that the per-batch step's results land in ([0:2] loss and accuracy of the fused step, [2]
         # a scalar variable fetched next to a train op): asynchronous copies and ONE event wait per sess.run instead
         # of a blocking ``.cpu()`` per fetched value (each ~20 us: a staged copy into pageable memory).
-        self._host_words = self._host_evt = None
+        self._host_words = self._host_evt = self._host_evt_var = None
         if self.device.type == "cuda":
             self._host_words = torch.zeros(4, dtype=torch.float32).pin_memory()
-            self._host_evt = torch.cuda.Event()
+            self._host_evt, self._host_evt_var = torch.cuda.Event(), torch.cuda.Event()
         # One thread at a time inside the session: a Supervisor's checkpoint thread pulls into the same slab and
         # staging buffers a training step is using (re-entrant: run() -> _pull(), Saver -> var_tensor()).
         import threading
@@ -364,7 +364,7 @@ class Session:
                         if self._host_words is not None and view.numel() == 1 and not pending_used:
                             with torch.cuda.device(self.device):
                                 self._host_words[2:3].copy_(view.reshape(1), non_blocking=True)
-                                pending = _PendingScalar(self._host_words, torch.cuda.Event(), 2)
+                                pending = _PendingScalar(self._host_words, self._host_evt_var, 2)
                                 pending.event.record()
                             cache[f] = pending
                             pending_used = True
