@@ -210,7 +210,8 @@ class Session:
             self.theta = self.store.bind_local()
         self.grad = self.layout.new_slab(self.device)
         self._engines: Dict[Any, MLPEngine] = {}
-        self._plans: Dict[int, Any] = {}
+        self._plans: Dict[int, Any] = {}          # train op -> what runs it (fused model, dense stack, accuracy nodes)
+        self._reads_vars: Dict[Any, bool] = {}    # node -> whether evaluating it reads variables
         self._replica_owner = None
         self._closed = False
         self.fused_steps = 0
@@ -386,13 +387,13 @@ class Session:
             return True
         if node.op in ("init_all", "init_vars", "no_op", "sync_init_tokens"):
             return False
-        key = ("rv", node)
-        if key in self._plans:
-            return self._plans[key]
+        key = node
+        if key in self._reads_vars:
+            return self._reads_vars[key]
         r = any(self._reads_variables(i) for i in node.inputs)
         if node.op in ("merge_summary", "scalar_summary", "gradient"):
             r = True
-        self._plans[key] = r
+        self._reads_vars[key] = r
         return r
 
     def _fetch(self, f, feed, cache):
@@ -789,7 +790,7 @@ class Session:
     def _try_fused_eval(self, f, feed, cache):
         """Loss / accuracy of the matched model over a fed batch, on the fused forward kernels."""
         for plan in list(self._plans.values()):
-            if not isinstance(plan, dict) or (plan.get("mlp") is None and plan.get("dense") is None):
+            if plan.get("mlp") is None and plan.get("dense") is None:
                 continue
             m = plan["mlp"] if plan.get("mlp") is not None else plan["dense"]
             is_loss = f is m["loss"]
