@@ -22,18 +22,23 @@
 // workgroups of unequal size through 768 slots: a ragged second round, and every row read three times.)
 // Consecutive units belong to at most 4 consecutive pairs, i.e. 5 consecutive batches, and a batch that is x_{j+1}
 // of one pair is x_j of the next: the workgroup stages each of its batches ONCE per chunk, as an image
-// [k-quad][116 rows][4 floats], and every wave reads its 16 A rows from one image and the 7 x 16 B rows from the
+// [k-quad][112 rows][4 floats], and every wave reads its 16 A rows from one image and the 7 x 16 B rows from the
 // image before it.  Rows are read ~1.6x (the batches at a workgroup's ends are also its neighbours', and neighbours
 // share an XCD and its L2).
 //
 // Staging.  K is walked in chunks of 64 floats (16 k-quads).  A wave-instruction loads 4 rows x 16 k-quads (256
 // contiguous bytes of each row) with lane -> (row l & 3, k-quad l >> 2); 25 row groups per batch, at most 125 of
-// them per workgroup and chunk = 8 loads per thread.  Rows per k-quad are padded to 116 so that consecutive
-// k-quads lie 16 banks apart: the 8 lanes of a ds_write_b128 group (4 rows of 2 k-quads) cover all 32 banks.  Lane
-// (i = l & 15, q = l >> 4) of a macro-step reads k-quad 4 ms + q of row i as one ds_read_b128: the 16 lanes of a
-// lane group read 256 contiguous bytes, no bank conflict.  MFMA s of the macro-step contracts k = 16 ms + 4 q + s
-// (component s of both operands).  Rows B..115 of an image are never written: Gram element (m, i) depends on A row
-// m and B row i alone, and rows or columns beyond B are not stored.  One LDS buffer and one register set: the loads
+// them per workgroup and chunk = 8 loads per thread.  The image holds row r of k-quad kq at row slot r ^ 4 (kq & 1) of
+// the k-quad's 112: a ds_write_b128 is served in groups of 8 contiguous lanes (4 rows of 2 consecutive k-quads, banks
+// modulo 32 dwords), and the flipped row bit puts the odd k-quad's rows into the other half of the 128 bytes.  A
+// ds_read_b128 is served in four groups of 16 NON-contiguous lanes ({0-3, 12-15, 20-27}, ...: rows 0-3 and 12-15 of
+// one lane quarter with rows 4-11 of the next, banks modulo 64 dwords): lane (i = l & 15, q = l >> 4) of a macro-step
+// reads k-quad 4 ms + {0, 2, 1, 3}[q] of row i, so that the two quarters of a group read k-quads of the same parity
+// and meet 16 different 16-byte slots (rows of 116 with the plain assignment measured 6.0 M conflict cycles of 15.5 M
+// LDS cycles per launch).  MFMA s of the macro-step contracts k = 16 ms + 4 {0, 2, 1, 3}[q] + s
+// (component s of both operands).  Rows B..111 of an image are never written (but for the zeros that unused load
+// slots drop into rows 104-111): Gram element (m, i) depends on A row m and B row i alone, and rows or columns
+// beyond B are not stored.  One LDS buffer and one register set: the loads
 // of chunk c+1 are issued while chunk c is multiplied, into the registers whose rows of chunk c have just been
 // stored.  The row that a thread loads is also the row it stores into the epoch-ordered copy if the row's unit (as
 // x_{j+1}) is one of the workgroup's (batch 0: the workgroup that owns unit 0).
@@ -46,7 +51,7 @@ constexpr int kChunkQ = 16;                 // k-quads per chunk (64 floats)
 constexpr int kRowsB = 112;                 // Gram columns with padding (7 block columns): the largest leading dimension
 constexpr int kPThreads = 1024;
 constexpr int kPWaves = kPThreads / 64;
-constexpr int kPRows = 116;                 // rows per k-quad of a batch image
+constexpr int kPRows = 112;                 // rows per k-quad of a batch image (7 MFMA blocks; 448 dwords = 0 modulo 64 banks)
 constexpr int kPMaxBat = 5;                 // batches that 16 consecutive units can touch
 constexpr int kPBat = kChunkQ * kPRows * 4; // floats per batch image (29,696 bytes)
 constexpr int kPLoads = 8;                  // wave-instructions per wave and chunk
@@ -112,8 +117,8 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
     const bool owned = bs < nbat && DTF_GRAM_OWNS(batch, rg >> 2);
     const bool needed = bs < nbat && (batch < b1 || owned);   // every row of a batch that is some pair's x_j here
     own |= (owned ? 1u : 0u) << u;
-    // an item beyond the workgroup's batches writes its zeros into rows that no product keeps (4 ngroups .. + 3 >= B)
-    ldsoff[u] = bs < nbat ? bs * (kPBat / 16) + rg : ngroups;
+    // an item beyond the workgroup's batches writes its zeros into rows that no product keeps (group 27: rows 104 - 111)
+    ldsoff[u] = bs < nbat ? bs * (kPBat / 16) + rg : 27;
     dstrow[u] = (unsigned)(batch * B + 4 * rg);
     const int row = 4 * rg + r4;
     const long erow = needed ? (long)batch * B + (row < B ? row : 0) : 0;
@@ -138,8 +143,10 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
   const bool wave_works = u0 + wave < u1;
   const int unit = wave_works ? u0 + wave : u0;
   const int pair = unit / kBlk, brow = unit - pair * kBlk;
-  const float* As = img + (pair + 1 - b0) * kPBat + (16 * brow + i16) * 4;
-  const float* Bs = img + (pair - b0) * kPBat + i16 * 4;
+  // (the image's swizzle and the k-quad a lane group takes: see "Staging" at the top)
+  const int i16x = i16 ^ ((q >> 1) << 2), kqsel = ((q & 1) << 1) | (q >> 1);
+  const float* As = img + (pair + 1 - b0) * kPBat + (kqsel * kPRows + 16 * brow + i16x) * 4;
+  const float* Bs = img + (pair - b0) * kPBat + (kqsel * kPRows + i16x) * 4;
 
   // the labels of the rows this workgroup stores travel with them, behind the first chunk's loads: a wave takes the
   // 16 rows of its own unit, four elements per lane at a time so that the loads of a turn are in flight together
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
     if (c < 20) DTF_GRAM_STAMP(2 + c);
 #pragma unroll
     for (int u = 0; u < kPLoads; ++u)
-      *reinterpret_cast<f32x4*>(img + 16 * ldsoff[u] + (kql * kPRows + r4) * 4) = stage[u];
+      *reinterpret_cast<f32x4*>(img + 16 * (ldsoff[u] ^ (kql & 1)) + (kql * kPRows + r4) * 4) = stage[u];
     __syncthreads();
     // The epoch-ordered copy is stored from the staging registers AFTER the barrier (no wave waits at the barrier for
     // another wave's global stores; streaming stores: nobody reads the copy before the kernel ends), and the loads
@@ -211,14 +218,14 @@ __global__ __launch_bounds__(kPThreads) void gather_gram_kernel(GramArgs a) {
     // B operands in two turns (4 + 3 blocks): 12 registers fewer than all seven at once
 #define DTF_GRAM_MACRO(ms)                                                                                         \
   do {                                                                                                             \
-    const f32x4 av = *reinterpret_cast<const f32x4*>(As + (4 * (ms) + q) * kPRows * 4);                            \
+    const f32x4 av = *reinterpret_cast<const f32x4*>(As + 4 * (ms) * kPRows * 4);                            \
     f32x4 bv[4];                                                                                                   \
     _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                                                               \
-        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + ((4 * (ms) + q) * kPRows + 16 * bi) * 4);                    \
+        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + (4 * (ms) * kPRows + 16 * bi) * 4);                    \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int bi = 0; bi < 4; ++bi)                 \
         acc[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[bi][s], acc[bi], 0, 0, 0);                        \
     _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                                                               \
-        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + ((4 * (ms) + q) * kPRows + 16 * (4 + bi)) * 4);              \
+        bv[bi] = *reinterpret_cast<const f32x4*>(Bs + (4 * (ms) * kPRows + 16 * (4 + bi)) * 4);              \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int bi = 0; bi < 3; ++bi)                 \
         acc[4 + bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[bi][s], acc[4 + bi], 0, 0, 0);                \
   } while (0)
