@@ -129,6 +129,21 @@ def _find_idx(data_dir: str, stem: str) -> Optional[str]:
     return None
 
 
+_LIVE_REORDERS = set()
+
+
+def _finish_reorders():
+    """At interpreter exit: let gathers that are under way end (tens of milliseconds) instead of leaving a thread inside
+    numpy while the interpreter is torn down."""
+    for t in list(_LIVE_REORDERS):
+        t.join(timeout=5.0)
+
+
+import atexit  # noqa: E402
+
+atexit.register(_finish_reorders)
+
+
 class _Reorder:
     """dst[i] = src[order[i]] for a pair of arrays on a background thread (numpy's take releases the interpreter lock)."""
 
@@ -147,9 +162,11 @@ class _Reorder:
 
         self._thread = threading.Thread(target=work, name="dtf-reshuffle", daemon=True)
         self._thread.start()
+        _LIVE_REORDERS.add(self._thread)
 
     def wait(self):
         self._thread.join()
+        _LIVE_REORDERS.discard(self._thread)
         if self.error is not None:
             raise self.error
         return self.result
