@@ -25,6 +25,16 @@ inline int grid_for(int64_t n_vec) {
   return (int)g;
 }
 
+// The step counter usually lives INSIDE the slab that an apply updates (it is a variable like the others, with a zero
+// gradient).  The kernels below bump it with one atomic, so nothing else may write it: a plain read-modify-write of the
+// vector that holds it -- by another thread of this launch, or by the launch of another worker that applies to the shard
+// at the same time without a lock -- could put an old count back.  Index of the counter inside [p, p + n), or -4
+// (no vector has index -1, no element index -4).
+__device__ __forceinline__ int64_t step_index_in(const float* p, int64_t n, const float* global_step) {
+  if (global_step == nullptr || global_step < p || global_step >= p + n) return -4;
+  return global_step - p;
+}
+
 __global__ __launch_bounds__(kBlock) void sgd_apply_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            int64_t n, const float* __restrict__ lr_ptr,
                                                            float scale, int zero_grad,
@@ -35,15 +45,21 @@ __global__ __launch_bounds__(kBlock) void sgd_apply_kernel(float* __restrict__ p
   f32x4* p4 = reinterpret_cast<f32x4*>(p);
   f32x4* g4 = reinterpret_cast<f32x4*>(g);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int64_t gs_at = step_index_in(p, n, global_step);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
     const f32x4 gv = g4[i];
-    p4[i] = p4[i] - a * gv;
+    if (i == (gs_at >> 2)) {
+      for (int e = 0; e < 4; ++e)
+        if (4 * i + e != gs_at) p[4 * i + e] -= a * gv[e];
+    } else {
+      p4[i] = p4[i] - a * gv;
+    }
     if (zero_grad) g4[i] = zero;
   }
   if (blockIdx.x == 0) {
     const int64_t t = (nvec << 2) + threadIdx.x;
     if (t < n) {
-      p[t] -= a * g[t];
+      if (t != gs_at) p[t] -= a * g[t];
       if (zero_grad) g[t] = 0.f;
     }
     // atomic: several workers (processes) may apply to the same shard concurrently — the lock-free
@@ -82,16 +98,22 @@ __global__ __launch_bounds__(kBlock) void sum_apply_kernel(float* __restrict__ p
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  const int64_t gs_at = step_index_in(p, n, global_step);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
     f32x4 sum = reinterpret_cast<const f32x4*>(s.g[0])[i];
 #pragma unroll
     for (int k = 1; k < kMaxSources; ++k)
       if (k < s.count) sum = sum + reinterpret_cast<const f32x4*>(s.g[k])[i];
-    p4[i] = p4[i] - a * sum;
+    if (i == (gs_at >> 2)) {
+      for (int e = 0; e < 4; ++e)
+        if (4 * i + e != gs_at) p[4 * i + e] -= a * sum[e];
+    } else {
+      p4[i] = p4[i] - a * sum;
+    }
   }
   if (blockIdx.x == 0) {
     const int64_t t = (nvec << 2) + threadIdx.x;
-    if (t < n) {
+    if (t < n && t != gs_at) {
       float sum = s.g[0][t];
 #pragma unroll
       for (int k = 1; k < kMaxSources; ++k)

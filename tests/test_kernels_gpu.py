@@ -477,3 +477,103 @@ def test_sgd_apply_atomic_loses_no_update_under_concurrent_streams():
                 hb.sgd_apply_atomic_(p, g, lr, 1.0, step)
     torch.cuda.synchronize()
     assert float(p.min()) == float(p.max()) == -100.0 and float(step) == 100.0
+
+
+def test_native_rounds_of_the_synchronous_chief_apply_regular_rounds_and_hand_back_the_rest():
+    """``dtf_sync_rounds`` (csrc/optim.hip) against a scripted barrier board: regular rounds (one arrival per worker, in
+    step, same mailbox row) are applied as p -= lr * mean(g) with the step counter bumped and tokens of step + 1 dealt;
+    an arrival out of step ends the call with the arrivals handed back and nothing applied; no arrivals: time-out."""
+    import ctypes as C
+
+    lib = hb.require()
+    lib.dtf_sync_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dtf_sync_rounds.restype = C.c_int
+    workers, n = 3, 1000
+    script = []            # per take(): list of (worker, step, slot)
+    released = []
+    TAKE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int))
+    RELEASE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int)
+
+    def take(board, want, timeout_ms, out, got):
+        if not script:
+            got[0] = 0
+            return 1
+        batch = script.pop(0)[:want]
+        for i, rec in enumerate(batch):
+            for j in range(3):
+                out[3 * i + j] = rec[j]
+        got[0] = len(batch)
+        return 0
+
+    def release(board, worker, step, copies):
+        released.append((worker, step, copies))
+        return 0
+
+    take_c, release_c = TAKE(take), RELEASE(release)
+    g = torch.Generator().manual_seed(4)
+    p = torch.randn(n + 4, generator=g).to(DEV)            # [n parameters][step counter + padding]
+    boxes = [[torch.randn(n + 4, generator=g).to(DEV) for _ in range(workers)] for _ in range(2)]     # [slot][worker]
+    for slot in boxes:
+        for b in slot:
+            b[n:] = 0.0
+    lr = torch.full((1,), 0.5, device=DEV)
+    params = (C.c_void_p * 1)(p.data_ptr())
+    tabs_keep = [(C.c_uint64 * workers)(*[b.data_ptr() for b in boxes[slot]]) for slot in (0, 1)]
+    tabs = (C.c_void_p * 2)(*[C.cast(t, C.c_void_p).value for t in tabs_keep])
+    numel = (C.c_int64 * 1)(n + 4)
+    gs = (C.c_void_p * 1)(p[n:n + 1].data_ptr())
+    out, got, rounds = (C.c_int64 * 48)(), C.c_int(0), C.c_int(0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(step, max_rounds):
+        return lib.dtf_sync_rounds(C.cast(take_c, C.c_void_p), C.cast(release_c, C.c_void_p), 1, workers, step, 50, 1, params,
+                                   tabs, numel, gs, lr.data_ptr(), 2, stream, max_rounds, out, C.byref(got), C.byref(rounds))
+
+    want = p.clone()
+    # two regular rounds (arrivals in two takes, any order), rows 0 and 1
+    script[:] = [[(2, 7, 0)], [(0, 7, 0), (1, 7, 0)], [(1, 8, 1), (0, 8, 1), (2, 8, 1)]]
+    assert call(7, 2) == 0 and rounds.value == 2 and released == [(-1, 8, 2), (-1, 9, 2)]
+    for slot in (0, 1):
+        want[:n] -= 0.5 * sum(b[:n] for b in boxes[slot]) / workers
+    want[n] += 2.0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(p, want, rtol=1e-6, atol=1e-6)
+    # an arrival of an older step: handed back, nothing applied, no token
+    script[:] = [[(0, 9, 0), (1, 8, 0), (2, 9, 0)]]
+    del released[:]
+    assert call(9, 4) == 1 and rounds.value == 0 and got.value == 3 and not released
+    assert [tuple(out[3 * i:3 * i + 3]) for i in range(3)] == [(0, 9, 0), (1, 8, 0), (2, 9, 0)]
+    # the same worker twice, and mixed mailbox rows: not a regular round either
+    script[:] = [[(0, 9, 0), (0, 9, 0), (2, 9, 0)]]
+    assert call(9, 1) == 1 and rounds.value == 0
+    script[:] = [[(0, 9, 0), (1, 9, 1), (2, 9, 0)]]
+    assert call(9, 1) == 1 and rounds.value == 0
+    # one regular round, then nothing arrives: the round counts, the call ends with a time-out and two arrivals in hand
+    script[:] = [[(0, 9, 1), (1, 9, 1), (2, 9, 1)], [(1, 10, 0), (2, 10, 0)]]
+    assert call(9, 3) == 2 and rounds.value == 1 and got.value == 2 and released == [(-1, 10, 2)]
+    want[:n] -= 0.5 * sum(b[:n] for b in boxes[1]) / workers
+    want[n] += 1.0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(p, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("where", [0, 501, 1002])
+def test_applies_from_two_streams_never_lose_a_count_of_a_step_counter_inside_the_slab(where):
+    """The counter is a variable of the slab like the others (zero gradient): the unlocked apply and the sum-apply bump it
+    with one atomic and keep every plain write away from it, wherever in the slab it lies -- two workers that apply to one
+    shard at the same time without a lock (use_locking=False, tfdist_between.py:65) may lose updates, never counts."""
+    n = 1003
+    p = torch.zeros(n, device=DEV)
+    g = torch.zeros(n, device=DEV)
+    lr = torch.full((1,), 0.1, device=DEV)
+    gs = p[where:where + 1]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(150):
+        for s in streams:
+            with torch.cuda.stream(s):
+                hb.sgd_apply_(p, g, lr, 1.0, False, gs)
+                hb.sum_apply_(p, [g, g], lr, 0.5, gs)
+    torch.cuda.synchronize()
+    assert float(p[where]) == 600.0 and float(p.abs().sum()) == 600.0
