@@ -208,7 +208,8 @@ template <int BM, int BN, int LAYOUT, bool VEC, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_f32_kernel(GemmArgs a) {
   constexpr bool AK = LAYOUT != DTF_GEMM_TN, BK = LAYOUT == DTF_GEMM_NT;
   constexpr int kThreads = NW * 64;
-  // The waves of a workgroup tile its output 2 x 2 (four waves: the 128-tile) or 2 x 4 (eight waves: the 64-tile).
+  // The waves of a workgroup tile its output 2 x 2 (four waves: the 128-tile) or 2 x 4 (eight waves: the 64-tile, and the
+  // 128-tile where a CU holds one workgroup anyway).
   // Eight waves on the 128-tile (four per SIMD with two workgroups per CU, 128 registers each) measured 108 - 120 TFLOP/s
   // against 117 - 126 with four, and did not fit its registers.  The 64-tile is what shapes with few tiles get, often ONE
   // workgroup per CU: with four waves that is one wave per SIMD, whose matrix instructions do not follow each other
@@ -539,6 +540,10 @@ int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
   const long small = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   const double t_big = (double)((big + 511) / 512), t_small = 0.55 * (double)((small + 1023) / 1024);
   if (tile == 128 || (tile == 0 && big >= 512 && t_big <= t_small)) return launch_gemm<128, 128, LAYOUT, VEC, 4>(a, stream);
+  // A grid of large tiles that fills the chip once without filling it twice (2048^3, 1024 x 4096 x 1024: 256 tiles)
+  // runs as ONE workgroup per CU; with eight waves (a 64 x 32 quadrant each, two waves per SIMD) that beats both four
+  // waves (one per SIMD) and the same work as 1024 small tiles: 2048^3 0.85 - 0.89 -> 0.92 - 0.97 of the library.
+  if (tile == 129 || (tile == 0 && big > 224 && big <= 256)) return launch_gemm<128, 128, LAYOUT, VEC, 8>(a, stream);
   // Between one and one and a half small tiles per CU (10000 x 100 x 784: 314 of them), the CUs with two set the time;
   // tiles of half the height spread the same work as three per CU at most: 32.7 -> 27.8 us there (NT).  Not for TN,
   // whose A arrives strided: a strided operand wants at least 64 rows or columns per tile (a wave's 64 lanes share one
@@ -834,7 +839,7 @@ extern "C" int dtf_gemm_f32_ws(int layout, int epi, const float* A, const float*
   if ((layout == DTF_GEMM_TN ? lda < M : lda < K) || (layout == DTF_GEMM_NT ? ldb < K : ldb < N)) return DTF_ERR_SHAPE;
   if (epi == DTF_EPI_ACT_BWD && (aux == nullptr || ldaux < N)) return DTF_ERR_NULL;
   if (epi == DTF_EPI_SGD && lr == nullptr) return DTF_ERR_NULL;
-  if (tile != 0 && tile != 32 && tile != 64 && tile != 128) return DTF_ERR_SHAPE;
+  if (tile != 0 && tile != 32 && tile != 64 && tile != 128 && tile != 129) return DTF_ERR_SHAPE;
   // byte offsets inside a tile (k along memory: 128 rows; k strided: the 32 rows of a chunk) are 32-bit
   if ((128 * lda + K) * 4 >= (1LL << 31) || (128 * ldb + K) * 4 >= (1LL << 31)) return DTF_ERR_UNSUPPORTED;
   GemmArgs a{};

@@ -326,7 +326,10 @@ def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EP
     layout ``GEMM_NN``: A [M,K], B [K,N]; ``GEMM_NT``: A [M,K], B [N,K]; ``GEMM_TN``: A [K,M], B [K,N].  Operands are
     row-major with contiguous rows (row strides may exceed the row length).  Epilogues: ``EPI_NONE`` ``scale * acc``;
     ``EPI_BIAS_ACT`` ``act(acc + bias)``; ``EPI_ACT_BWD`` ``acc * act'(aux)`` (aux = the activation's output);
-    ``EPI_SGD`` ``out -= lr * scale * acc`` (lr: one-element device tensor)."""
+    ``EPI_SGD`` ``out -= lr * scale * acc`` (lr: one-element device tensor).
+
+    ``tile``: 0 = chosen from the shape; 128 / 129 = 128 x 128 tiles with four / eight waves; 64 = 64 x 64 tiles (eight
+    waves); 32 = 32 x 64 tiles (NN and NT only)."""
     lib = require()
     _f32_2d(A, "A"), _f32_2d(B, "B")
     if layout == GEMM_NN:

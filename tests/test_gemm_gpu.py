@@ -28,7 +28,7 @@ SHAPES = [(128, 128, 64), (100, 100, 784), (1, 1, 1), (33, 37, 50), (130, 257, 7
 
 @pytest.mark.parametrize("layout", [hb.GEMM_NN, hb.GEMM_NT, hb.GEMM_TN])
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 129])        # 129: the 128-tile with eight waves
 def test_gemm_plain(layout, M, N, K, tile):
     a, b, want = _operands(layout, M, N, K, seed=11)
     got = hb.gemm(layout, a, b, tile=tile)
