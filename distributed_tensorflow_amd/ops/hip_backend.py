@@ -238,11 +238,23 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
-def _stream() -> int:
+def _stream(operand: Optional[torch.Tensor] = None) -> int:
     """Handle of the current stream of the current device.  (``torch.cuda.current_stream()`` resolves its device
-    through ``torch.cuda.is_available()``, a driver call of ~12 us: too much for a call made before every launch.)"""
+    through ``torch.cuda.is_available()``, a driver call of ~12 us: too much for a call made before every launch.)
+
+    ``operand``: a tensor of the launch.  The kernels run on the calling thread's CURRENT device (and set their
+    per-device attributes there); an operand that lives on another GPU means the caller forgot to make that GPU
+    current (``torch.cuda.device(...)``; a new thread starts on device 0), and the launch would read memory the
+    current device has no mapping of: refuse it loudly instead."""
     if _raw_stream is not None and _raw_device is not None:
-        return _raw_stream(_raw_device())
+        dev = _raw_device()
+        if operand is not None and operand.device.index != dev:
+            raise HipKernelError(f"operand on {operand.device} but the current device of this thread is cuda:{dev}: "
+                                 f"enter torch.cuda.device({str(operand.device)!r}) around the call")
+        return _raw_stream(dev)
+    if operand is not None and operand.device.index != torch.cuda.current_device():
+        raise HipKernelError(f"operand on {operand.device} but the current device of this thread is "
+                             f"cuda:{torch.cuda.current_device()}")
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -265,7 +277,7 @@ def linear_bias_act(x, W, b, act: int, out: Optional[torch.Tensor] = None) -> to
         raise HipKernelError(f"linear_bias_act shape mismatch x{tuple(x.shape)} W{tuple(W.shape)} b{tuple(b.shape)}")
     if out is None:
         out = torch.empty((M, H), device=x.device, dtype=torch.float32)
-    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), _ptr(b), _ptr(out), M, K, H, act, 1, _stream()),
+    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), _ptr(b), _ptr(out), M, K, H, act, 1, _stream(x)),
            "dtf_linear_bias_act")
     return out
 
@@ -280,7 +292,7 @@ def linear_splitk(x, W, ksplit: int, out: Optional[torch.Tensor] = None) -> torc
         raise HipKernelError("linear_splitk shape mismatch")
     if out is None:
         out = torch.zeros((M, H), device=x.device, dtype=torch.float32)
-    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), None, _ptr(out), M, K, H, 0, int(ksplit), _stream()),
+    _check(lib.dtf_linear_bias_act(_ptr(x), _ptr(W), None, _ptr(out), M, K, H, 0, int(ksplit), _stream(x)),
            "dtf_linear_bias_act(splitk)")
     return out
 
@@ -297,7 +309,7 @@ def dw_gemm(x, dz, out: Optional[torch.Tensor] = None, mode: int = 0, scale: flo
         out = torch.zeros((K, H), device=x.device, dtype=torch.float32)
     if tuple(out.shape) != (K, H):
         raise HipKernelError("dw_gemm: bad output shape")
-    _check(lib.dtf_dw_gemm(_ptr(x), _ptr(dz), _ptr(out), M, K, H, mode, float(scale), _ptr(lr), _stream()),
+    _check(lib.dtf_dw_gemm(_ptr(x), _ptr(dz), _ptr(out), M, K, H, mode, float(scale), _ptr(lr), _stream(x)),
            "dtf_dw_gemm")
     return out
 
@@ -360,7 +372,7 @@ def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EP
     _check(lib.dtf_gemm_f32_ws(layout, epi, _ptr(A), _ptr(B), _ptr(out), M, N, K, A.stride(0), B.stride(0), out.stride(0),
                                int(act), _ptr(bias), _ptr(aux), aux.stride(0) if aux is not None else 0, _ptr(lr),
                                float(scale), int(tile), _ptr(workspace), workspace.numel() if workspace is not None else 0,
-                               int(splits), _stream()), "dtf_gemm_f32")
+                               int(splits), _stream(A)), "dtf_gemm_f32")
     return out
 
 
@@ -384,7 +396,7 @@ def colsum(z, out: Optional[torch.Tensor] = None, *, sgd: bool = False, lr: Opti
     if sgd and (lr is None or _f32c(lr, "lr").numel() != 1):
         raise HipKernelError("colsum: the SGD form needs a one-element device learning rate")
     _check(lib.dtf_colsum(_ptr(z), z.stride(0), M, N, _ptr(out), EPI_SGD if sgd else EPI_NONE, float(scale), _ptr(lr),
-                          _stream()), "dtf_colsum")
+                          _stream(z)), "dtf_colsum")
     return out
 
 
@@ -438,7 +450,7 @@ def softmax_xent(logits, labels, *, dz: Optional[torch.Tensor] = None, grad_scal
     if row_loss is not None and _f32c(row_loss, "row_loss").numel() != M:
         raise HipKernelError("softmax_xent: row_loss has one element per row")
     _check(lib.dtf_softmax_xent(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(loss_sum),
-                                _ptr(correct), _ptr(row_loss), _stream()), "dtf_softmax_xent")
+                                _ptr(correct), _ptr(row_loss), _stream(logits)), "dtf_softmax_xent")
 
 
 # Up to here the one-workgroup head is used: one row per wave.  Beyond, its waves walk several rows one after the other,
@@ -459,7 +471,7 @@ def softmax_xent_step(logits, labels, dz: torch.Tensor, grad_scale: float, loss_
         raise HipKernelError("softmax_xent_step: one float32 loss and one int32 count")
     M, Cn = logits.shape
     _check(lib.dtf_softmax_xent_step(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(loss_out),
-                                     _ptr(correct_out), _ptr(global_step), _stream()), "dtf_softmax_xent_step")
+                                     _ptr(correct_out), _ptr(global_step), _stream(logits)), "dtf_softmax_xent_step")
 
 
 def xent_head_scratch(rows: int, device) -> torch.Tensor:
@@ -480,7 +492,7 @@ def softmax_xent_head(logits, labels, dz: torch.Tensor, grad_scale: float, scrat
         raise HipKernelError("softmax_xent_head: one float32 loss and one int32 count")
     M, Cn = logits.shape
     _check(lib.dtf_softmax_xent_head(_ptr(logits), _ptr(labels), M, Cn, _ptr(dz), float(grad_scale), _ptr(scratch),
-                                     scratch.numel(), _ptr(loss_out), _ptr(correct_out), _ptr(global_step), _stream()),
+                                     scratch.numel(), _ptr(loss_out), _ptr(correct_out), _ptr(global_step), _stream(logits)),
            "dtf_softmax_xent_head")
 
 
@@ -499,7 +511,7 @@ def sgd_apply_(p, g, lr: torch.Tensor, scale: float = 1.0, zero_grad: bool = Fal
     if p.numel() != g.numel():
         raise HipKernelError("sgd_apply: size mismatch")
     _check(lib.dtf_sgd_apply(_ptr(p), _ptr(g), p.numel(), _ptr(lr), float(scale), int(zero_grad),
-                             _ptr(global_step), _stream()), "dtf_sgd_apply")
+                             _ptr(global_step), _stream(p)), "dtf_sgd_apply")
     return p
 
 
@@ -510,7 +522,7 @@ def sgd_apply_atomic_(p, g, lr: torch.Tensor, scale: float = 1.0, global_step: O
     if p.numel() != g.numel():
         raise HipKernelError("sgd_apply_atomic: size mismatch")
     _check(lib.dtf_sgd_apply_atomic(_ptr(p), _ptr(g), p.numel(), _ptr(lr), float(scale), _ptr(global_step),
-                                    _stream()), "dtf_sgd_apply_atomic")
+                                    _stream(p)), "dtf_sgd_apply_atomic")
     return p
 
 
@@ -532,7 +544,7 @@ def sum_apply_(p, grads, lr: torch.Tensor, scale: float = 1.0, global_step: Opti
         raise HipKernelError("sum_apply: 1..16 gradient sources")
     tab = (C.c_uint64 * len(ptrs))(*ptrs)
     _check(lib.dtf_sum_apply(_ptr(p), tab, len(ptrs), p.numel(), _ptr(lr), float(scale), _ptr(global_step),
-                             _stream()), "dtf_sum_apply")
+                             _stream(p)), "dtf_sum_apply")
     return p
 
 
@@ -541,7 +553,7 @@ def accumulate_(acc, g):
     _f32c(acc, "acc"), _f32c(g, "g")
     if acc.numel() != g.numel():
         raise HipKernelError("accumulate: size mismatch")
-    _check(lib.dtf_accumulate(_ptr(acc), _ptr(g), acc.numel(), _stream()), "dtf_accumulate")
+    _check(lib.dtf_accumulate(_ptr(acc), _ptr(g), acc.numel(), _stream(acc)), "dtf_accumulate")
     return acc
 
 
@@ -549,7 +561,7 @@ def philox_normal_(out, seed: int, offset: int = 0, mean: float = 0.0, stddev: f
     lib = require()
     _f32c(out, "out")
     _check(lib.dtf_philox_normal(_ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset), float(mean),
-                                 float(stddev), _stream()), "dtf_philox_normal")
+                                 float(stddev), _stream(out)), "dtf_philox_normal")
     return out
 
 
@@ -598,7 +610,7 @@ def gather_rows(src, idx, out: Optional[torch.Tensor] = None):
         raise HipKernelError(f"gather_rows: launched with cuda:{torch.cuda.current_device()} current on tensors of "
                              f"{src.device} (the launch would go to another device's stream)")
     err = _gather_err_word(src.device)
-    _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, src.shape[0], _ptr(err), _stream()),
+    _check(lib.dtf_gather_rows(_ptr(src), _ptr(idx), _ptr(out), rows, cols, src.shape[0], _ptr(err), _stream(src)),
            "dtf_gather_rows")
     return out
 
@@ -631,7 +643,7 @@ def gather_gram(src, perm, dst, gram, B: int, nb: int, ysrc=None, ydst=None):
         raise HipKernelError(f"gather_gram: tensors on {src.device} / {perm.device} / {gram.device}, launched with "
                              f"cuda:{torch.cuda.current_device()} current")
     _check(lib.dtf_gather_gram(_ptr(src), _ptr(perm), _ptr(dst), _ptr(gram), src.shape[0], int(B), K, int(nb),
-                               gram.shape[2], _ptr(ysrc) if ydst is not None else None, _ptr(ydst), C_, _stream()),
+                               gram.shape[2], _ptr(ysrc) if ydst is not None else None, _ptr(ydst), C_, _stream(src)),
            "dtf_gather_gram")
     return gram
 
@@ -646,7 +658,7 @@ def mlp_eval(x, y, W1, b1, W2, b2, act: int, a2_ws, loss_sum, correct):
     if W1.shape != (K, H) or y.shape != (M, Cc) or a2_ws.numel() < M * H or correct.dtype != torch.int32:
         raise HipKernelError("mlp_eval: shape mismatch")
     _check(lib.dtf_mlp_eval(_ptr(x), _ptr(y), M, K, H, Cc, act, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                            _ptr(a2_ws), _ptr(loss_sum), _ptr(correct), _stream()), "dtf_mlp_eval")
+                            _ptr(a2_ws), _ptr(loss_sum), _ptr(correct), _stream(x)), "dtf_mlp_eval")
 
 
 def mlp_step_fused(desc: DtfMlpDesc, batch_index: int, parity: int):
@@ -690,11 +702,11 @@ def transpose(src: torch.Tensor, dst: torch.Tensor):
     _f32c(src, "src"), _f32c(dst, "dst")
     if src.dim() != 2 or dst.shape != (src.shape[1], src.shape[0]) or dst.device != src.device:
         raise HipKernelError("transpose: dst must be shaped like src.T on the same device")
-    _check(require().dtf_transpose(_ptr(src), _ptr(dst), src.shape[0], src.shape[1], _stream()), "dtf_transpose")
+    _check(require().dtf_transpose(_ptr(src), _ptr(dst), src.shape[0], src.shape[1], _stream(src)), "dtf_transpose")
 
 
 def advance_cursor(cursor: torch.Tensor, n: int):
-    _check(require().dtf_advance_cursor(_ptr(cursor), int(n), _stream()), "dtf_advance_cursor")
+    _check(require().dtf_advance_cursor(_ptr(cursor), int(n), _stream(cursor)), "dtf_advance_cursor")
 
 
 def enable_peer_access(device: torch.device, peer: torch.device) -> None:

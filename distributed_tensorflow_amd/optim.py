@@ -101,6 +101,7 @@ class QueueRunner:
         store = sess.store
         if not getattr(store, "is_remote", False):
             return   # a local session aggregates inline
+        sess.bind_thread()       # (the chief's applies belong on the session's GPU; a new thread starts on device 0)
         clients = store.aggregator_clients()
         required = opt.replicas_to_aggregate
         idle_since = None

@@ -24,6 +24,7 @@ reference pays too; the device-resident fast tier (``parallel.replicas``,
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 from typing import Any, Dict, List, Optional, Sequence
@@ -196,6 +197,7 @@ class Session:
             raise ValueError(f"unknown session target {target!r}: create the task's Server first")
         self.config = config or (self.server.config if self.server else ConfigProto())
         self.device = self._resolve_device()
+        self.bind_thread()
         specs = [v.spec for v in self.graph.variables]
         n_shards = self.server.num_ps if (self.server and self.server.num_ps > 0) else 1
         if n_shards == 1:
@@ -288,9 +290,25 @@ class Session:
     def as_default(self):
         return self
 
+    def bind_thread(self) -> None:
+        """Make the session's GPU the calling thread's current device.  The native launches go to the current device's
+        current stream and set per-device kernel attributes there, and the current device is a property of the THREAD
+        (a new thread starts on device 0): the constructor does this for its own thread, a service thread that works
+        on the session's store (the Supervisor's checkpoint loop, the chief's aggregation loop) calls it first.  With
+        worker k on GPU k (tfdist_between.py:34) device 0 would be the wrong one for every worker but the first."""
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+
+    def _on_device(self):
+        """Context for entry points any thread may call: the session's GPU is the current device inside."""
+        if self.device.type != "cuda" or torch.cuda.current_device() == self.device.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
+
     def close(self):
         if not self._closed:
-            self.store.close()
+            with self._on_device():
+                self.store.close()
             self._closed = True
 
     # -- variables ------------------------------------------------------------------
@@ -308,7 +326,7 @@ class Session:
         # (a checkpoint of the Supervisor's thread, an evaluation) would silently set this worker back.
         if self._replica_owner is not None:
             return
-        with self.run_lock, span("pull"):
+        with self.run_lock, self._on_device(), span("pull"):
             self.store.pull(self.theta)
 
     def own_replica(self, owner) -> None:
@@ -329,9 +347,9 @@ class Session:
         if options is not None and getattr(options, "wants_trace", False):
             col = run_metadata.step_stats.collector if run_metadata is not None else Collector()
             col.sync = bool(options.wants_device_time)
-            with self.run_lock, col, span("session.run"):
+            with self.run_lock, self._on_device(), col, span("session.run"):
                 return self._run(fetches, feed_dict)
-        with self.run_lock:
+        with self.run_lock, self._on_device():
             return self._run(fetches, feed_dict)
 
     def _run(self, fetches, feed_dict):

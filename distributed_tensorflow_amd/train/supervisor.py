@@ -161,6 +161,7 @@ class Supervisor:
         return [t]
 
     def _checkpoint_loop(self, sess: Session):
+        sess.bind_thread()       # (this thread's launches and copies belong on the session's GPU, not on device 0)
         while not self.coord.wait_for_stop(self.save_model_secs):
             try:
                 self.saver.save(sess, self.save_path, global_step=self._step_value(sess))

@@ -577,3 +577,42 @@ def test_applies_from_two_streams_never_lose_a_count_of_a_step_counter_inside_th
                 hb.sum_apply_(p, [g, g], lr, 0.5, gs)
     torch.cuda.synchronize()
     assert float(p[where]) == 600.0 and float(p.abs().sum()) == 600.0
+
+
+def test_a_launch_with_an_operand_of_another_gpu_than_the_threads_current_one_is_refused(monkeypatch):
+    """The kernels run on the calling thread's current device; with worker k on GPU k (tfdist_between.py:34) a thread
+    still on device 0 must hear about it, not fault.  (One GPU here: the current device is faked.)"""
+    from distributed_tensorflow_amd.ops import hip_backend as hb
+
+    p = torch.zeros(64, device="cuda")
+    g = torch.ones(64, device="cuda")
+    lr = torch.tensor([0.5], device="cuda")
+    hb.sgd_apply_(p, g, lr)
+    assert torch.allclose(p, torch.full_like(p, -0.5))
+    monkeypatch.setattr(hb, "_raw_device", lambda: 1)
+    with pytest.raises(hb.HipKernelError, match="current device"):
+        hb.sgd_apply_(p, g, lr)
+
+
+def test_a_session_makes_its_gpu_the_current_device_of_its_service_threads():
+    import threading
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.examples.mnist_mlp import build_model
+
+    g = tf.Graph()
+    with g.as_default():
+        build_model(0.1)
+    sess = tf.Session(graph=g)
+    seen = []
+
+    def service():
+        sess.bind_thread()
+        seen.append(torch.cuda.current_device())
+        with sess._on_device():
+            seen.append(torch.cuda.current_device())
+
+    t = threading.Thread(target=service)
+    t.start()
+    t.join()
+    assert seen == [sess.device.index, sess.device.index]
+    sess.close()
