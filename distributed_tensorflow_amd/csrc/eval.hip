@@ -26,6 +26,7 @@
 #include "dtf_api.h"
 #include "dtf_common.h"
 #include "dtf_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -394,15 +395,15 @@ int dtf_launch_eval_fused(const float* x, const float* y, int M, int K, int H, i
                           const float* b1, const float* W2, const float* b2, float* loss_sum, int* correct,
                           hipStream_t stream) {
   if (!dtf_eval_fused_supported(M, K, H, C) || (reinterpret_cast<uintptr_t>(x) & 15u)) return DTF_ERR_SHAPE;
-  static unsigned long long configured = 0;            // one bit per device: the attribute belongs to the device's copy
+  static std::atomic<unsigned long long> configured{0};    // one bit per device: the attribute belongs to the device's copy
   constexpr int bytes = kSmemFloats * (int)sizeof(float);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
-  if (dev >= 64 || !((configured >> dev) & 1ull)) {
+  if (dev >= 64 || !((configured.load(std::memory_order_acquire) >> dev) & 1ull)) {
     if (hipFuncSetAttribute((const void*)eval_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) !=
         hipSuccess)
       return DTF_ERR_LAUNCH;
-    if (dev < 64) configured |= 1ull << dev;
+    if (dev < 64) configured.fetch_or(1ull << dev, std::memory_order_release);
   }
   EvalArgs a{x, y, W1, b1, W2, b2, loss_sum, correct, M, K, H, C, act, g_eval_stamps, g_eval_parts};
   const int blocks = (M + kRows - 1) / kRows;

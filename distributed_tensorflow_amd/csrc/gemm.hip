@@ -33,6 +33,7 @@
 #include "dtf_common.h"
 #include "dtf_internal.h"
 
+#include <atomic>
 #include <type_traits>
 
 #ifndef DTF_GEMM_DEPTH64
@@ -497,14 +498,14 @@ template <int BM, int BN, int LAYOUT, bool VEC, int NW = 4>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int kThreads = NW * 64;
   constexpr int bytes = 2 * kKQ * (BM + BN) * 4 * (int)sizeof(float);
-  static unsigned long long configured = 0;            // one bit per device: the attribute belongs to the device's copy
+  static std::atomic<unsigned long long> configured{0};    // one bit per device: the attribute belongs to the device's copy
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
-  if (dev >= 64 || !((configured >> dev) & 1ull)) {
+  if (dev >= 64 || !((configured.load(std::memory_order_acquire) >> dev) & 1ull)) {
     if (hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, LAYOUT, VEC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             bytes) != hipSuccess)
       return DTF_ERR_LAUNCH;
-    if (dev < 64) configured |= 1ull << dev;
+    if (dev < 64) configured.fetch_or(1ull << dev, std::memory_order_release);
   }
   GemmArgs b = a;
   b.tiles_m = (a.M + BM - 1) / BM;

@@ -21,6 +21,7 @@
 // the general form (p * sum(y) - y)/B.
 #include "dtf_api.h"
 #include "dtf_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -413,7 +414,7 @@ int pick_rows(int M, int H) {
   return R;
 }
 
-unsigned long long g_attr_set = 0;
+std::atomic<unsigned long long> g_attr_set{0};
 long long* g_stamps = nullptr;   // device buffer of 16 {wall, cycle} pairs, or null
 
 }  // namespace
@@ -433,11 +434,11 @@ int dtf_launch_head(const DtfHeadLaunch& a, hipStream_t stream) {
   if (a.mode == DTF_HEAD_FUSED && grid != 1) return DTF_ERR_UNSUPPORTED;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DTF_ERR_LAUNCH;
-  if (dev >= 64 || !((g_attr_set >> dev) & 1ull)) {   // one bit per device: the attribute belongs to the device's copy
+  if (dev >= 64 || !((g_attr_set.load(std::memory_order_acquire) >> dev) & 1ull)) {   // one bit per device: the attribute belongs to the device's copy
     if (hipFuncSetAttribute((const void*)mlp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return DTF_ERR_LAUNCH;
-    if (dev < 64) g_attr_set |= 1ull << dev;
+    if (dev < 64) g_attr_set.fetch_or(1ull << dev, std::memory_order_release);
   }
   HeadParams p;
   p.zin = a.zin; p.pre_act = a.pre_act; p.zero_zin = a.zero_zin;
