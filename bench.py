@@ -29,8 +29,8 @@ test-set evaluation, tfdist_between.py:86-111) and is always measured.
 With one GPU the line also carries the reference's scripts in their literal form, run as child processes after the
 headline: ``sec_per_epoch_per_batch_tier`` (``tfsingle.py``: one ``sess.run`` with feed and four fetches and one event
 record per batch; DTF_BENCH_PER_BATCH=0 skips it) and ``per_batch_clusters`` (``tfdist_between.py`` /
-``tfdist_between_sync.py`` as separate ps and worker tasks sharing the GPU: asynchronous 1 ps + 1 worker and
-1 ps + 2 workers, synchronous 1 ps + 2 workers; DTF_BENCH_CLUSTERS=0 skips it, on the CPU it runs only with =1).
+``tfdist_between_sync.py`` as separate ps and worker tasks sharing the GPU: asynchronous 1 ps + 1 worker,
+1 ps + 2 workers and 2 ps + 2 workers, synchronous 1 ps + 2 workers; DTF_BENCH_CLUSTERS=0 skips it, on the CPU it runs only with =1).
 """
 from __future__ import annotations
 

@@ -311,8 +311,9 @@ def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float =
 
 def _child_clusters(use_cpu: bool, limit_s: float = 60.0) -> dict:
     """The reference's between-graph recipes as it runs them (README.md:88-113, 150-176 there): the repository's
-    ``tfdist_between.py`` / ``tfdist_between_sync.py`` as one process per task -- asynchronous 1 ps + 1 worker and
-    1 ps + 2 workers, synchronous 1 ps + 2 workers -- with all tasks on this GPU and the shards in the ps task's HBM
+    ``tfdist_between.py`` / ``tfdist_between_sync.py`` as one process per task -- asynchronous 1 ps + 1 worker,
+    1 ps + 2 workers and 2 ps + 2 workers (the variables dealt round-robin over the two shards), synchronous 1 ps +
+    2 workers -- with all tasks on this GPU and the shards in the ps task's HBM
     (``--transport=ipc``; on the CPU, where the stage only runs when DTF_BENCH_CLUSTERS=1 asks for it: tcp and 1,100
     training rows).  Reports the slowest worker's fastest epoch
     after the first, from the scripts' own epoch clocks."""
@@ -330,7 +331,7 @@ def _child_clusters(use_cpu: bool, limit_s: float = 60.0) -> dict:
                    + ("tcp shards on the host" if use_cpu else "shards in the ps task's HBM (HIP-IPC)")
                    + "; the slowest worker's fastest epoch after the first"}
     for key, script, n_ps, n_w in (("async_1ps_1w", "tfdist_between.py", 1, 1), ("async_1ps_2w", "tfdist_between.py", 1, 2),
-                                   ("sync_1ps_2w", "tfdist_between_sync.py", 1, 2)):
+                                   ("async_2ps_2w", "tfdist_between.py", 2, 2), ("sync_1ps_2w", "tfdist_between_sync.py", 1, 2)):
         try:
             r = run_local_cluster(script, n_ps, n_w, "tcp" if use_cpu else "ipc", epochs=4, extra=extra, timeout=limit_s,
                                   env=env)

@@ -43,14 +43,16 @@ def test_single_process_defaults_to_one_gpu_and_reports_the_contract_fields():
 
 def test_per_batch_cluster_stage_reports_the_reference_recipes():
     """DTF_BENCH_CLUSTERS=1 (the default on a GPU): the between-graph scripts as separate tasks, one sess.run per batch --
-    asynchronous 1 ps + 1 worker and 1 ps + 2 workers, synchronous 1 ps + 2 workers -- next to the headline."""
+    asynchronous 1 ps + 1 worker, 1 ps + 2 workers and 2 ps + 2 workers, synchronous 1 ps + 2 workers -- next to the
+    headline."""
     env = dict(os.environ, DTF_BENCH_CLUSTERS="1", DTF_BENCH_PER_BATCH="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu", "--steps", "10", "--warmup", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     r = _json_line(p.stdout)
     c = r["per_batch_clusters"]
-    for key, workers, steps in (("async_1ps_1w", 1, 4 * 11), ("async_1ps_2w", 2, 2 * 4 * 11), ("sync_1ps_2w", 2, 4 * 11)):
+    for key, workers, steps in (("async_1ps_1w", 1, 4 * 11), ("async_1ps_2w", 2, 2 * 4 * 11), ("async_2ps_2w", 2, 2 * 4 * 11),
+                                ("sync_1ps_2w", 2, 4 * 11)):
         assert "sec_per_epoch" in c[key], c[key]
         assert r[f"sec_per_epoch_{key}_per_batch"] == c[key]["sec_per_epoch"] > 0 and c[key]["workers"] == workers
         # asynchronous workers print the step they pulled before their own update: up to workers - 1 short of the total
