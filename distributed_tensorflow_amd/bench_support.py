@@ -268,7 +268,7 @@ def _child_dense_dp(rank: int, dev_index: int, world: int, backend: str, limit_s
     return {"error": f"{note}: {text[-300:]}"}
 
 
-def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 100.0) -> dict:
+def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float = 100.0, one_device: bool = False) -> dict:
     """In-graph replication measured by a client process of its own (``bench.py --mode ingraph``): one engine per
     process is how the engine is used and tested, and a rank that has built half a dozen trainers before is not that;
     whatever happens to the client stays in the client."""
@@ -286,6 +286,11 @@ def _child_ingraph(n: int, steps: int, warmup: int, chunk: int, limit_s: float =
     # the client itself, not a launcher with the client as ITS child (which a kill at the time limit would orphan); and
     # its own watchdog ends it should the kill not reach it
     env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DTF_BENCH_DEADLINE_S=str(int(limit_s)))
+    if one_device and int(env.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        # towers that share a GPU (the rehearsal on a one-GPU machine) wait for each other inside their launches and
+        # need a hardware queue each: the client asks the runtime for 16 (read when the runtime starts) and may then
+        # run four towers instead of two
+        env["GPU_MAX_HW_QUEUES"] = "16"
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=limit_s)
         text, note = r.stdout, f"client exited {r.returncode}"
@@ -796,7 +801,8 @@ def run_benchmark(args) -> Optional[dict]:
                 else:
                     # (default: a client process of its own -- a fault on a node this code has never run on then
                     # costs this stage, not the line rank 0 is about to print)
-                    rep = _child_ingraph(n, min(steps, 4 * bpe), min(warmup, bpe), int(args.chunk))
+                    rep = _child_ingraph(n, min(steps, 4 * bpe), min(warmup, bpe), int(args.chunk),
+                                         one_device=share_gpu or torch.cuda.device_count() < n)
             except Exception as e:  # noqa: BLE001
                 rep = {"error": f"{type(e).__name__}: {e}"}
             result_extra["ingraph_mode"] = rep
@@ -962,12 +968,14 @@ def _measure_dense_stacks(device) -> dict:
 def _measure_ingraph(n, one_device: bool, mnist, warmup: int, steps: int, chunk: int, test_x, test_y, use_cpu: bool) -> dict:
     """In-graph replication measured from ONE process: N towers (one per GPU; all on GPU 0 in the one-GPU
     rehearsal, limited to 2 towers there: the streams of one process share 4 hardware queues per GPU, and a
-    third tower's spinning backward launch can be queued behind the launch it waits for)."""
+    third tower's spinning backward launch can be queued behind the launch it waits for -- or to 4 towers when the
+    process was started with GPU_MAX_HW_QUEUES >= 16, as the benchmark's in-graph client is; six towers' spinning
+    backward workgroups no longer fit the chip together and time out)."""
     from .parallel.towers import InGraphEngine
 
     if use_cpu:
         raise RuntimeError("the in-graph engine is a GPU path")
-    towers = n if not one_device else min(n, 2)
+    towers = n if not one_device else min(n, 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 16 else 2)
     devices = [torch.device("cuda", 0 if one_device else i) for i in range(towers)]
     out = {}
     for exchange in ("inbox", "rccl"):

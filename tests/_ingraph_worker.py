@@ -15,11 +15,12 @@ from distributed_tensorflow_amd.parallel.towers import InGraphEngine  # noqa: E4
 
 def main():
     towers, compact = int(sys.argv[1]), sys.argv[2] == "1"
+    timeout_ms = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
     rng = np.random.RandomState(0)
     images = rng.rand(600, 784).astype(np.float32)
     labels = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 600)]
     eng = InGraphEngine(["cuda:0"] * towers, images, labels, batch=100, lr=0.05, seed=1, chunk=4, compact=compact,
-                        timeout_ms=20000)
+                        timeout_ms=timeout_ms)
     res = {}
     try:
         p = {k: v.detach().cpu().clone() for k, v in eng.towers[0].layout.mlp_views(eng.towers[0].params).items()}

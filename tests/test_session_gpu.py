@@ -323,20 +323,23 @@ def test_double_buffered_dataset_gives_the_same_run():
     assert a.ds.epoch == b.ds.epoch == 2 and a.ds.active == 0
 
 
-def test_in_graph_script_drives_two_towers_with_one_graph_launch_per_tower_and_chunk(tmp_path):
-    """tfdist.py (in-graph replication): one client, two towers (sharing the GPU here), hipGraph chunks per tower,
-    gradient mean inside the backward launches; same stdout contract as the other scripts."""
+@pytest.mark.parametrize("towers", [2, 4])
+def test_in_graph_script_drives_its_towers_with_one_graph_launch_per_tower_and_chunk(towers, tmp_path):
+    """tfdist.py (in-graph replication): one client, two or four towers (sharing the GPU here; for four the script
+    asks the runtime for a hardware queue per tower before its first GPU call), hipGraph chunks per tower, gradient
+    mean inside the backward launches; same stdout contract as the other scripts."""
     import re
     import subprocess
     import sys
 
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tfdist.py"), "--num_towers=2", "--epochs=2",
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tfdist.py"), f"--num_towers={towers}", "--epochs=2",
                         "--train_size=2200", "--freq=11", "--lr=0.01", f"--logs_path={tmp_path}"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=200)
+                       cwd=ROOT, capture_output=True, text=True, timeout=200, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     out = p.stdout
-    assert "in-graph: 1 client, 2 towers" in out and "inside the towers' backward launches" in out
-    assert "tower_1: /job:localhost/replica:0/task:0/gpu:0" in out and out.rstrip().endswith("Done")
+    assert f"in-graph: 1 client, {towers} towers" in out and "inside the towers' backward launches" in out
+    assert f"tower_{towers - 1}: /job:localhost/replica:0/task:0/gpu:0" in out and out.rstrip().endswith("Done")
     steps = [int(v) for v in re.findall(r"Step: (\d+),", out)]
     costs = [float(c) for c in re.findall(r"Cost: ([\d.]+)", out)]
     assert steps[-1] == 2 * 22 and costs[-1] < costs[0]          # one averaged update per step of both towers

@@ -206,17 +206,21 @@ def test_stream_probe_tells_streams_on_one_hardware_queue_from_streams_that_run_
 
 @pytest.mark.gpu
 @pytest.mark.timeout(200)
-@pytest.mark.parametrize("towers,compact", [(2, False), (2, True)])
+@pytest.mark.parametrize("towers,compact", [(2, False), (2, True), (4, False), (4, True)])
 def test_in_graph_engine_towers_on_one_gpu_match_the_mean_gradient_oracle(towers, compact):
     """ONE client process, a stream and hipGraph chunks per tower, gradient mean inside the backward launches
     (plain pointers between the towers): bit-identical replicas that follow the CPU oracle of synchronous SGD
-    on the mean of the towers' gradients, with one host call per tower per chunk.  (Two towers: the streams of one
-    process share 4 hardware queues, and a third tower's spinning backward can end up queued behind a peer's.)"""
+    on the mean of the towers' gradients, with one host call per tower per chunk.  (The streams of one process share
+    4 hardware queues by default, and a third tower's spinning backward can end up queued behind a peer's: the client
+    of four towers on ONE GPU asks the runtime for 16 queues.  Towers on GPUs of their own need no such thing.)"""
     from cluster_utils import ROOT
 
+    env = dict(os.environ)
+    if towers > 2:
+        env["GPU_MAX_HW_QUEUES"] = "16"
     # a process of its own: one engine per client process is how the engine is used
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ingraph_worker.py"), str(towers), str(int(compact))],
-                         cwd=ROOT, capture_output=True, text=True, timeout=180)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ingraph_worker.py"), str(towers), str(int(compact)),
+                          "5000"], cwd=ROOT, capture_output=True, text=True, timeout=180, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
     assert res["healthy_5"], "an exchange between the towers timed out"

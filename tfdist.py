@@ -13,6 +13,7 @@ mean is taken inside the towers' backward launches through peer access — one h
 Every tower trains on its own shuffled copy of the data with batch_size samples per step,
 so one step consumes num_towers * batch_size samples and makes ONE averaged update.
 """
+import os
 import time
 
 import distributed_tensorflow_amd as tf
@@ -32,15 +33,23 @@ def main(_):
 
     mnist = mnist_mlp.load_data(FLAGS)
     print("worker setting up ...", flush=True)
-    n_gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    n_gpu = torch.cuda.device_count()          # (counting the GPUs does not start the HIP runtime)
     n = FLAGS.num_towers or max(n_gpu, 1)
+    # Towers that share a GPU must all be resident on it at once to swap gradients inside their launches, each on a
+    # hardware queue of its own: at most two per GPU with the four queues a process gets by default, four per GPU
+    # with sixteen (more towers' waiting workgroups no longer fit the chip together).  The runtime reads the number
+    # when it starts, at the first GPU call: ask for it here.
+    per_gpu = -(-n // n_gpu) if n_gpu else 0
+    if 2 < per_gpu <= 4 and FLAGS.exchange != "rccl" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    per_gpu_limit = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 16 else 2
+    if n_gpu and not torch.cuda.is_available():
+        n_gpu = 0
     devices = [f"cuda:{i % n_gpu}" for i in range(n)] if n_gpu else ["cpu"] * n
     begin_time = time.time()
     exchange = FLAGS.exchange
     if exchange == "auto":
-        # towers that share a GPU must all be resident on it at once to swap gradients inside their launches:
-        # at most two per GPU (the streams of one process share four hardware queues)
-        crowded = n_gpu and max(devices.count(d) for d in devices) > 2
+        crowded = n_gpu and per_gpu > per_gpu_limit
         exchange = "inbox" if (n_gpu and not crowded and FLAGS.activation == "sigmoid") else "rccl"
     hidden = mnist_mlp.hidden_widths(FLAGS)
     if hidden != (100,) and n_gpu and FLAGS.exchange != "rccl" and max(devices.count(d) for d in devices) <= 2:
