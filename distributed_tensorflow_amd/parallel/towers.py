@@ -93,13 +93,19 @@ class InGraphTowers:
         if self.use_rccl:
             import torch.cuda.nccl as nccl
 
-            nccl.all_reduce(self.grads)
-        else:
-            total = self.grads[0].clone()
-            for g in self.grads[1:]:
-                total += g.to(total.device)
-            for g in self.grads:
-                g.copy_(total.to(g.device))
+            try:
+                nccl.all_reduce(self.grads)
+                return
+            except (RuntimeError, AttributeError) as e:
+                # (a build of the library without the single-process binding: the sum below gives the same mean)
+                print(f"[towers] torch.cuda.nccl.all_reduce is not usable here ({type(e).__name__}: {e}); "
+                      f"summing the towers' gradients in this process instead", flush=True)
+                self.use_rccl = False
+        total = self.grads[0].clone()
+        for g in self.grads[1:]:
+            total += g.to(total.device)
+        for g in self.grads:
+            g.copy_(total.to(g.device))
 
     def step(self):
         pos = self.steps % self.batches_per_epoch

@@ -228,3 +228,18 @@ def test_in_graph_engine_towers_on_one_gpu_match_the_mean_gradient_oracle(towers
     assert res["oracle_error"] <= 1.0, res          # |got - oracle| <= 2e-5 + 2e-4 |oracle| everywhere
     assert res["healthy_14"] and res["identical_14"] and res["step_14"] == 14
     assert res["loss"] == res["loss"] and 0.0 <= res["acc"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_the_single_process_all_reduce_binding_of_the_host_loop_towers_reaches_rccl():
+    """``InGraphTowers`` with a tower per GPU sums the gradient slabs with ``torch.cuda.nccl.all_reduce`` (one process,
+    a list of tensors, one per GPU).  One GPU here: a list of one tensor goes through the same binding into RCCL
+    (communicator of one rank, the kernel launch) and must come back unchanged."""
+    import torch
+    import torch.cuda.nccl as nccl
+
+    g = torch.arange(1000, dtype=torch.float32, device="cuda")
+    assert nccl.is_available([g])
+    nccl.all_reduce([g])
+    torch.cuda.synchronize()
+    assert torch.equal(g.cpu(), torch.arange(1000, dtype=torch.float32))
