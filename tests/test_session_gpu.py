@@ -346,21 +346,24 @@ def test_in_graph_script_drives_its_towers_with_one_graph_launch_per_tower_and_c
     assert len(re.findall(r"Test-Accuracy: ([\d.]+)", out)) == 2
 
 
-def test_in_graph_script_with_a_deeper_stack_on_the_gpu(tmp_path):
-    """tfdist.py --hidden 64,32 --num_towers 2 (towers sharing the GPU: in-process sum of the gradient slabs): the
-    dense-layer kernels per tower, one averaged update per step, the reference's progress lines."""
+@pytest.mark.parametrize("towers", [2, 4])
+def test_in_graph_script_with_a_deeper_stack_on_the_gpu(towers, tmp_path):
+    """tfdist.py --hidden 64,32 --num_towers 2 | 4 (towers sharing the GPU; four: the script asks for a hardware queue
+    per tower): the dense-layer kernels per tower, one averaged update per step, the reference's progress lines."""
     import os
     import subprocess
     import sys
 
     from cluster_utils import ROOT
 
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tfdist.py"), "--hidden", "64,32", "--activation", "relu",
-                          "--num_towers", "2", "--lr", "0.05", "--epochs", "2", "--train_size", "2200", "--logs_path",
+                          "--num_towers", str(towers), "--lr", "0.05", "--epochs", "2", "--train_size", "2200", "--logs_path",
                           str(tmp_path)], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                         timeout=200, env=dict(os.environ, PYTHONPATH=ROOT))
+                         timeout=200, env=dict(env, PYTHONPATH=ROOT))
     assert out.returncode == 0, out.stdout[-2000:]
-    assert "2 towers of a dense stack 784-64-32-10" in out.stdout and "tower_1: /job:localhost/replica:0/task:0/gpu:0" in out.stdout
+    assert f"{towers} towers of a dense stack 784-64-32-10" in out.stdout
+    assert f"tower_{towers - 1}: /job:localhost/replica:0/task:0/gpu:0" in out.stdout
     assert "Step: 44,  Epoch:  2,  Batch:  22 of  22" in out.stdout and out.stdout.rstrip().endswith("Done")
     accs = [float(line.split(":")[1]) for line in out.stdout.splitlines() if line.startswith("Test-Accuracy")]
     assert len(accs) == 2 and accs[-1] > 0.5

@@ -52,7 +52,7 @@ def main(_):
         crowded = n_gpu and per_gpu > per_gpu_limit
         exchange = "inbox" if (n_gpu and not crowded and FLAGS.activation == "sigmoid") else "rccl"
     hidden = mnist_mlp.hidden_widths(FLAGS)
-    if hidden != (100,) and n_gpu and FLAGS.exchange != "rccl" and max(devices.count(d) for d in devices) <= 2:
+    if hidden != (100,) and n_gpu and FLAGS.exchange != "rccl" and per_gpu <= per_gpu_limit:
         # any other stack on GPUs: a stream and hipGraph chunks per tower, the stack's gradient launches and one
         # exchange kernel per step (sum of the towers' gradient slabs through peer access + SGD)
         towers = DenseInGraphEngine(devices, mnist.train.images, mnist.train.labels, FLAGS.batch_size, FLAGS.lr,
