@@ -90,6 +90,9 @@ struct Stager {
   int K;
   int wave, lane, tid;
   unsigned voff[NV];       // bytes from the descriptor's base: the per-lane part of every address
+  unsigned vcol;           // strided form: the column part of voff[0] alone (see kq_lane)
+  int kq_lane;             // strided form with R < 64: k-quads between this lane and lane 0 of its wave (0 or 1, ...);
+                           //   that part of the address is per lane and sits in voff[0], the wave's part is scalar
   bool ok[NV];             // the slot's row / column lies inside the operand
   int lds0;                // floats: LDS offset of slot 0 (slot j: + kLdsStep * j)
   bool interior;
@@ -117,7 +120,10 @@ struct Stager {
     } else {
       const int c = tid % R;
       ok[0] = r0 + c < rows;
-      voff[0] = (unsigned)((ok[0] ? c : rows - 1 - r0) * 4);
+      vcol = (unsigned)((ok[0] ? c : rows - 1 - r0) * 4);
+      // R >= 64: a wave's lanes share one k-quad.  R = 32: lanes 32-63 hold the next one, 4 rows of the operand on.
+      kq_lane = tid / R - __builtin_amdgcn_readfirstlane(tid / R);
+      voff[0] = vcol + (unsigned)((long)(4 * kq_lane) * ld * 4);
       lds0 = ((tid / R) * R + c) * 4;
     }
   }
@@ -142,15 +148,26 @@ struct Stager {
       }
     } else {
       const __amdgpu_buffer_rsrc_t rsrc = descriptor(origin + (long)k0 * ld);      // the chunk's first row
-      const int kq_w = __builtin_amdgcn_readfirstlane(tid / R);                    // uniform within a wave
+      const int kq_w = __builtin_amdgcn_readfirstlane(tid / R);                    // lane 0's k-quad: uniform in a wave
+      if (full) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j)
+        for (int j = 0; j < NS; ++j)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          int kk = 4 * (kq_w + kQStep * j) + s;
-          kk = (full || k0 + kk < K) ? kk : 0;
-          v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[0], (int)(kk * ld * 4), 0));
-        }
+          for (int s = 0; s < 4; ++s)
+            v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       rsrc, voff[0], (int)((4 * (kq_w + kQStep * j) + s) * ld * 4), 0));
+      } else {
+        // the last chunk of a K that is no multiple of 32: the whole address per lane, a k past the end reads the
+        // chunk's first row instead (and is zeroed on its way to LDS)
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int kk = 4 * (kq_w + kq_lane + kQStep * j) + s;
+            const unsigned off = k0 + kk < K ? vcol + (unsigned)((long)kk * ld * 4) : vcol;
+            v[S][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+          }
+      }
     }
   }
   // The same two steps for a tile that lies inside the operand and a chunk that lies inside K: straight-line code (no
@@ -546,16 +563,14 @@ int launch_layout(const GemmArgs& a, int tile, hipStream_t stream) {
   // waves (one per SIMD) and the same work as 1024 small tiles: 2048^3 0.85 - 0.89 -> 0.92 - 0.97 of the library.
   if (tile == 129 || (tile == 0 && big > 224 && big <= 256)) return launch_gemm<128, 128, LAYOUT, VEC, 8>(a, stream);
   // Between one and one and a half small tiles per CU (10000 x 100 x 784: 314 of them), the CUs with two set the time;
-  // tiles of half the height spread the same work as three per CU at most: 32.7 -> 27.8 us there (NT).  Not for TN,
-  // whose A arrives strided: a strided operand wants at least 64 rows or columns per tile (a wave's 64 lanes share one
-  // k-quad), and not where K is split (few tiles).
-  if (LAYOUT != DTF_GEMM_TN) {
+  // tiles of half the height spread the same work as three per CU at most: 32.7 -> 27.8 us there (NT).  (TN: A arrives
+  // strided, and the two halves of a wave then stage neighbouring k-quads of the tile's 32 rows.)  Not where K is split
+  // (few tiles).
+  {
     const long half = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
     const long load_small = (small + 255) / 256 * 2, load_half = (half + 255) / 256;
     if (tile == 32 || (tile == 0 && small > 256 && 5 * load_half <= 4 * load_small))
       return launch_gemm<32, 64, LAYOUT, VEC, 4>(a, stream);
-  } else if (tile == 32) {
-    return DTF_ERR_UNSUPPORTED;
   }
   return launch_gemm<64, 64, LAYOUT, VEC, 8>(a, stream);
 }

@@ -341,7 +341,7 @@ def gemm(layout: int, A, B, out: Optional[torch.Tensor] = None, *, epi: int = EP
     ``EPI_SGD`` ``out -= lr * scale * acc`` (lr: one-element device tensor).
 
     ``tile``: 0 = chosen from the shape; 128 / 129 = 128 x 128 tiles with four / eight waves; 64 = 64 x 64 tiles (eight
-    waves); 32 = 32 x 64 tiles (NN and NT only)."""
+    waves); 32 = 32 x 64 tiles."""
     lib = require()
     _f32_2d(A, "A"), _f32_2d(B, "B")
     if layout == GEMM_NN:
