@@ -150,6 +150,12 @@ int dtf_xgmi_close(void* p);
 int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
                              float* params, int64_t n, const float* lr, float* global_step, uint32_t* state,
                              int rank, int world, int timeout_ms, void* stream);
+// The same with backup replicas (SyncReplicasOptimizer with replicas_to_aggregate < total_num_replicas): the sum runs
+// over the first `required` replicas to arrive in this exchange, every replica applies it.  required = 0 or world:
+// the call above.  state: four words (the fourth receives the mask of the replicas that counted).
+int dtf_xgmi_allreduce_apply_subset(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
+                                    float* params, int64_t n, const float* lr, float* global_step, uint32_t* state,
+                                    int rank, int world, int required, int timeout_ms, void* stream);
 // Two-launch step of a synchronous replica whose backward exchanges per element (mlp_step2.hip, XgParams).
 typedef struct DtfXgDesc {
   uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox: 2 slots (even / odd exchange

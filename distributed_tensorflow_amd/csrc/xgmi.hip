@@ -52,6 +52,7 @@ struct XgmiArgs {
   uint32_t* state;
   int rank, world;
   int64_t timeout_ticks;
+  int required;                      // subset form only: how many of the `world` gradients count (the first to arrive)
 };
 
 template <int W>
@@ -155,6 +156,120 @@ __global__ __launch_bounds__(kBlock) void xgmi_allreduce_apply_kernel(XgmiArgs a
   if (tid == 0) {
     if (failed && !poisoned) atomicExch(&a.state[kError], 1u);
     // Plain counting: the end of the kernel publishes everything to the next launch on this stream.
+    const uint32_t done = __hip_atomic_fetch_add(&a.state[kDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {      // last block out: the next launch sees seq + 1
+      __hip_atomic_store(&a.state[kDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.state[kSeq], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- the same exchange with BACKUP replicas: the first `required` of the `world` gradients count --------------------
+// SyncReplicasOptimizer(replicas_to_aggregate = R < total_num_replicas = N) (tfdist_between_sync.py:66-67 passes equal
+// values; the optimizer it calls takes fewer): an update is the mean of the first R gradients that arrive for a step, the
+// other N - R are dropped, every replica goes on with the same new values.
+//
+//   ticket     thread 0 of block 0 draws the replica's arrival number for exchange s from ONE 8-byte word
+//              {s, arrivals so far} in replica 0's flag memory (compare-and-swap at system scope; the word of the
+//              exchange two before, same parity, is recycled by whoever arrives first);
+//   announce   {s, ticket} goes into slot (s & 1, rank) of EVERY replica's flag array, the replica's own included
+//              (release: the gradient slab is complete);
+//   wait       every block polls its local array until all N slots carry s -- all of them: the replicas keep one copy
+//              of the variables each and stay in step, what the backup semantics change is whose gradients are summed --
+//              and notes which replicas drew a ticket below R;
+//   reduce     the members' slabs are added in rank order (the others' are not even read) and applied.
+// The backward kernels scale their gradients by 1 / R.  Slots alternate with the parity of s: a replica that is one
+// exchange ahead announces into the other slot, and it cannot be two ahead (it needs this replica's announcement of
+// s + 1 first).  state[3] keeps the member mask of the last exchange.
+constexpr int kAnnounce = 32;        // first word of the 2 x 16 announcement slots in a flag array
+constexpr int kTicketWord = 64;      // index, in 8-byte words, of the two ticket words in replica 0's flag memory
+
+__global__ __launch_bounds__(kBlock) void xgmi_allreduce_apply_subset_kernel(XgmiArgs a) {
+  __shared__ int failed;
+  __shared__ uint32_t members, announce;
+  const int tid = threadIdx.x;
+  const int world = a.world;
+  const uint32_t seq = __hip_atomic_load(&a.state[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t poisoned = __hip_atomic_load(&a.state[kError], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    failed = poisoned ? 1 : 0;
+    members = 0u;
+  }
+  const int64_t nvec = a.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t first = (int64_t)blockIdx.x * kBlock + tid;
+  f32x4* p4 = reinterpret_cast<f32x4*>(a.params);
+  const float lr = *a.lr;
+  const int slot0 = kAnnounce + 16 * (int)(seq & 1u);
+  __syncthreads();
+
+  if (!poisoned) {
+    if (blockIdx.x == 0) {
+      if (tid == 0) {
+        uint64_t* word = reinterpret_cast<uint64_t*>(a.peer_flags[0]) + kTicketWord + (seq & 1u);
+        uint64_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t ticket;
+        for (;;) {
+          const bool current = (uint32_t)(seen >> 32) == seq;
+          ticket = current ? (uint32_t)seen : 0u;
+          const uint64_t want = ((uint64_t)seq << 32) | (uint64_t)(ticket + 1u);
+          if (__hip_atomic_compare_exchange_strong(word, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM))
+            break;
+        }
+        announce = (seq << 4) | (ticket < 15u ? ticket : 15u);
+      }
+      __syncthreads();                                  // (block 0 only: the branch is uniform within a block)
+      if (tid < world) {
+        uint32_t* theirs = const_cast<uint32_t*>(a.my_flags);
+        for (int k = 0; k < world; ++k) theirs = (tid == k && k != a.rank) ? a.peer_flags[k] : theirs;
+        __hip_atomic_store(&theirs[slot0 + a.rank], announce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (tid < world) {
+      const long long t0 = wall_clock64();
+      for (;;) {
+        const uint32_t w = __hip_atomic_load(&a.my_flags[slot0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((w >> 4) == seq) {
+          if ((int)(w & 15u) < a.required) atomicOr(&members, 1u << tid);
+          break;
+        }
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (!failed) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: the members' slabs are read fresh
+      const uint32_t mask = members;
+      for (int64_t i = first; i < nvec; i += stride) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r)                 // rank order: identical bits on every replica
+          if ((mask >> r) & 1u) sum = sum + reinterpret_cast<const f32x4*>(pick<0>(a.grad, r, world))[i];
+        p4[i] = p4[i] - lr * sum;
+      }
+      if (blockIdx.x == 0) {
+        const int64_t t = (nvec << 2) + tid;
+        if (t < a.n) {
+          float sum = 0.f;
+          for (int r = 0; r < world; ++r)
+            if ((mask >> r) & 1u) sum += pick<0>(a.grad, r, world)[t];
+          a.params[t] -= lr * sum;
+        }
+        if (tid == 0) {
+          if (a.global_step) *a.global_step += 1.0f;   // (after thread 0's own write of vector 0, in program order)
+          a.state[3] = mask;
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  if (tid == 0) {
+    if (failed && !poisoned) atomicExch(&a.state[kError], 1u);
     const uint32_t done = __hip_atomic_fetch_add(&a.state[kDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {      // last block out: the next launch sees seq + 1
       __hip_atomic_store(&a.state[kDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -358,8 +473,21 @@ extern "C" int dtf_xgmi_close(void* p) {
 extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
                                         float* params, int64_t n, const float* lr, float* global_step,
                                         uint32_t* state, int rank, int world, int timeout_ms, void* stream) {
+  return dtf_xgmi_allreduce_apply_subset(grads, peer_flags, my_flags, params, n, lr, global_step, state, rank, world, 0,
+                                         timeout_ms, stream);
+}
+
+// The same with backup replicas: `required` in 1 .. world - 1 sums the gradients of the first `required` replicas to
+// arrive (see xgmi_allreduce_apply_subset_kernel; `state` then has four words, the fourth receives the member mask, and
+// the flag arrays are at least 1 KB); 0 or `world`: every replica's gradient, the kernel above.
+extern "C" int dtf_xgmi_allreduce_apply_subset(const uint64_t* grads, const uint64_t* peer_flags, const uint32_t* my_flags,
+                                               float* params, int64_t n, const float* lr, float* global_step,
+                                               uint32_t* state, int rank, int world, int required, int timeout_ms,
+                                               void* stream) {
   if (!grads || !peer_flags || !my_flags || !params || !lr || !state) return DTF_ERR_NULL;
   if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world || n < 0) return DTF_ERR_SHAPE;
+  if (required < 0 || required > world) return DTF_ERR_SHAPE;
+  if (required == world) required = 0;
   if (!aligned16(params)) return DTF_ERR_SHAPE;
   XgmiArgs a;
   for (int r = 0; r < kMaxRanks; ++r) {
@@ -376,11 +504,16 @@ extern "C" int dtf_xgmi_allreduce_apply(const uint64_t* grads, const uint64_t* p
   a.rank = rank;
   a.world = world;
   a.timeout_ticks = (int64_t)(timeout_ms > 0 ? timeout_ms : 5000) * 100000;   // 100 MHz wall clock
+  a.required = required;
   int64_t blocks = ((n >> 2) + kBlock - 1) / kBlock;
   if (blocks < 1) blocks = 1;
   if (blocks > 256) blocks = 256;      // every block must be resident while it waits
   const dim3 grid((unsigned)blocks), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
+  if (required > 0) {
+    hipLaunchKernelGGL(xgmi_allreduce_apply_subset_kernel, grid, block, 0, s, a);
+    return hipGetLastError() == hipSuccess ? DTF_OK : DTF_ERR_LAUNCH;
+  }
   switch (world) {
     case 1: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<1>, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(xgmi_allreduce_apply_kernel<2>, grid, block, 0, s, a); break;

@@ -47,9 +47,11 @@ def define_hparam_flags():
     f.DEFINE_string("hidden", "100", "widths of the hidden layers, comma-separated: 100 is the reference's network, "
                                      "e.g. 512,256 a deeper stack on the dense-layer kernels")
     f.DEFINE_boolean("resident", False, "device-resident hipGraph loop instead of one sess.run per batch.  Synchronous "
-                     "replicas in this tier keep one replica per worker and sum EVERY worker's gradient inside their "
-                     "kernels: replicas_to_aggregate must equal total_num_replicas (backup workers, "
-                     "replicas_to_aggregate < total_num_replicas, run in the per-batch tier: tcp and ipc transports)")
+                     "replicas in this tier keep one replica per worker and sum the workers' gradients inside their "
+                     "kernels (with backup workers, --replicas_to_aggregate below the number of workers: the first "
+                     "gradients to arrive, decided inside the exchange kernel)")
+    f.DEFINE_integer("replicas_to_aggregate", 0, "synchronous scripts: gradients per update (0: the number of workers, "
+                     "as the reference; fewer: the slowest workers' gradients of a step are dropped -- backup workers)")
     f.DEFINE_boolean("summaries", True, "write cost/accuracy summaries every step")
     f.DEFINE_integer("max_steps", 0, "stop after this many batches in total (0: run all epochs)")
     f.DEFINE_string("transport", "tcp", "parameter-server transport: tcp | ipc")
@@ -65,13 +67,13 @@ def hidden_widths(flags) -> tuple:
     return tuple(int(v) for v in str(getattr(flags, "hidden", "100")).split(",") if v.strip())
 
 
-def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0, hidden=(100,)):
+def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0, hidden=(100,), aggregate: int = 0):
     """The reference graph; call inside the ``tf.device(...)`` scope that places it.  ``hidden``: widths of the hidden
     layers — (100,) is the reference's network (tfdist_between.py:48-59), more entries give the same graph with more
     fully connected layers (variables still created weights first, then biases, as the reference does)."""
     hidden = tuple(int(h) for h in hidden)
     if len(hidden) != 1:
-        return _build_deep_model(lr, activation, sync_replicas, hidden)
+        return _build_deep_model(lr, activation, sync_replicas, hidden, aggregate)
     global_step = tf.get_variable("global_step", [], initializer=tf.constant_initializer(0), trainable=False)
     with tf.name_scope("input"):
         x = tf.placeholder(tf.float32, shape=[None, 784], name="x-input")
@@ -93,7 +95,7 @@ def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0, 
         opt = tf.train.GradientDescentOptimizer(lr)
         sync_opt = None
         if sync_replicas:
-            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=sync_replicas,
+            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=aggregate or sync_replicas,
                                                       total_num_replicas=sync_replicas, use_locking=True)
             train_op = sync_opt.minimize(cross_entropy, global_step=global_step)
         else:
@@ -109,7 +111,7 @@ def build_model(lr: float, activation: str = "sigmoid", sync_replicas: int = 0, 
                            sync_opt=sync_opt)
 
 
-def _build_deep_model(lr: float, activation: str, sync_replicas: int, hidden):
+def _build_deep_model(lr: float, activation: str, sync_replicas: int, hidden, aggregate: int = 0):
     """The reference graph with ``len(hidden)`` hidden layers (none: softmax regression).  Weights are drawn with
     standard deviation 1 / sqrt(fan-in): the reference's N(0, 1) saturates every unit of a second hidden layer."""
     dims = (784,) + tuple(hidden) + (10,)
@@ -135,7 +137,7 @@ def _build_deep_model(lr: float, activation: str, sync_replicas: int, hidden):
         opt = tf.train.GradientDescentOptimizer(lr)
         sync_opt = None
         if sync_replicas:
-            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=sync_replicas,
+            sync_opt = tf.train.SyncReplicasOptimizer(opt, replicas_to_aggregate=aggregate or sync_replicas,
                                                       total_num_replicas=sync_replicas, use_locking=True)
             train_op = sync_opt.minimize(cross_entropy, global_step=global_step)
         else:
@@ -287,7 +289,8 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
     n_workers = cluster.num_tasks("worker")
     with tf.device(tf.train.replica_device_setter(
             worker_device="/job:worker/task:%d/gpu:%d" % (flags.task_index, flags.task_index), cluster=cluster)):
-        m = build_model(flags.lr, flags.activation, sync_replicas=n_workers if sync else 0, hidden=hidden_widths(flags))
+        m = build_model(flags.lr, flags.activation, sync_replicas=n_workers if sync else 0, hidden=hidden_widths(flags),
+                        aggregate=int(flags.replicas_to_aggregate) if sync else 0)
         print("Ready to go")
     is_chief = flags.task_index == 0
     sv = tf.train.Supervisor(is_chief=is_chief, global_step=m.global_step, init_op=m.init_op,

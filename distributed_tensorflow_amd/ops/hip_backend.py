@@ -127,6 +127,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_xgmi_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.dtf_xgmi_close.argtypes = [vp]
     lib.dtf_xgmi_allreduce_apply.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
+    lib.dtf_xgmi_allreduce_apply_subset.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.dtf_mlp_step_xg.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, C.POINTER(DtfXgDesc), vp]
     lib.dtf_mlp_step_xg.restype = C.c_int
     lib.dtf_mlp_step_async.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, C.POINTER(DtfXgDesc), vp]
@@ -141,7 +142,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_transpose.restype = C.c_int
     for name in ("dtf_xgmi_pull", "dtf_xgmi_push_sgd", "dtf_xgmi_pull_ranges", "dtf_xgmi_fill",
                  "dtf_xgmi_max_ranks", "dtf_xgmi_alloc", "dtf_xgmi_free",
-                 "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply"):
+                 "dtf_xgmi_export", "dtf_xgmi_open", "dtf_xgmi_close", "dtf_xgmi_allreduce_apply",
+                 "dtf_xgmi_allreduce_apply_subset"):
         getattr(lib, name).restype = C.c_int
     lib.dtf_gemm_f32.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, i64, vp, f32, i32, vp]
     lib.dtf_gemm_f32_ws.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, vp, vp, i64, vp, f32, i32, vp,

@@ -475,10 +475,12 @@ class PsDenseSyncResidentTrainer:
         if self.device.type != "cuda":
             raise RuntimeError("the device-resident synchronous tier needs GPU workers")
         self.rank, self.world = sess.server.task_index, sess.server.num_workers
-        if opt.replicas_to_aggregate != self.world or opt.total_num_replicas != self.world:
-            raise ValueError("the resident synchronous tier aggregates every worker's gradient: "
-                             "replicas_to_aggregate and total_num_replicas must equal the number of workers "
-                             "(backup workers are served by the per-batch tier: run without --resident)")
+        if opt.total_num_replicas != self.world or not 1 <= opt.replicas_to_aggregate <= self.world:
+            raise ValueError("the resident synchronous tier keeps one replica per worker: total_num_replicas must equal "
+                             "the number of workers and replicas_to_aggregate must not exceed it")
+        # backup workers (replicas_to_aggregate < total_num_replicas): the mean of the first R gradients to arrive,
+        # decided inside the exchange kernel; every worker still takes part in every step (it keeps a replica)
+        self.required = 0 if opt.replicas_to_aggregate == self.world else int(opt.replicas_to_aggregate)
         self.chunk = max(1, int(chunk))
         self.use_graph = bool(use_graph)
         layout = sess.layout
@@ -511,16 +513,17 @@ class PsDenseSyncResidentTrainer:
     def describe(self) -> str:
         return (f"between-graph sync worker {self.rank} of {self.world}, device-resident, dense stack "
                 + "-".join(str(n) for n in self.engine.dims) + f": replica per worker, {self.engine.launches_per_step} "
-                f"launches + one exchange kernel per step over peer-mapped HBM (mean of {self.world}, one update per "
-                f"{self.world} batches)" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
+                f"launches + one exchange kernel per step over peer-mapped HBM (mean of "
+                + (f"the first {self.required} of {self.world} gradients to arrive" if self.required else f"{self.world}")
+                + f", one update per {self.world} batches)" + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
     _schedule = PsDenseResidentTrainer._schedule
     _bind_active_set = PsDenseResidentTrainer._bind_active_set
 
     def _one_step(self, bi: int, slot: int):
         self.engine.bind_grads(self._gsets[slot])
-        self.engine.step_grad(bi, 1.0 / self.world)
-        self.xg.apply(self.params, self.lr, slot, self.global_step)
+        self.engine.step_grad(bi, 1.0 / (self.required or self.world))
+        self.xg.apply(self.params, self.lr, slot, self.global_step, required=self.required)
 
     def _graph(self, pos: int, n: int, parity: int):
         key = (pos, n, parity, self._bound_set)

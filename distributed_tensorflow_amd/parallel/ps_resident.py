@@ -244,10 +244,12 @@ class PsSyncResidentTrainer(_BaseTrainer):
             raise RuntimeError("the device-resident synchronous tier needs GPU workers")
         self.ds = dataset
         self.rank, self.world = sess.server.task_index, sess.server.num_workers
-        if opt.replicas_to_aggregate != self.world or opt.total_num_replicas != self.world:
-            raise ValueError("the resident synchronous tier aggregates every worker's gradient: "
-                             "replicas_to_aggregate and total_num_replicas must equal the number of workers "
-                             "(backup workers are served by the per-batch tier: run without --resident)")
+        if opt.total_num_replicas != self.world or not 1 <= opt.replicas_to_aggregate <= self.world:
+            raise ValueError("the resident synchronous tier keeps one replica per worker: total_num_replicas must equal "
+                             "the number of workers and replicas_to_aggregate must not exceed it")
+        # backup workers (replicas_to_aggregate < total_num_replicas): the mean of the first R gradients to arrive,
+        # decided inside the one-kernel exchange; every worker still takes part in every step (it keeps a replica)
+        self.required = 0 if opt.replicas_to_aggregate == self.world else int(opt.replicas_to_aggregate)
         self.chunk = max(1, int(chunk))
         self.use_graph = bool(use_graph)
         self.layout = sess.layout
@@ -276,6 +278,8 @@ class PsSyncResidentTrainer(_BaseTrainer):
         forced = os.environ.get("DTF_SYNC_RESIDENT_EXCHANGE", "")
         self.exchange = forced if forced in ("inbox", "kernel") else (
             "kernel" if sharing > MAX_SPINNING_PER_GPU else "inbox")
+        if self.required:
+            self.exchange = "kernel"         # (the exchange that knows arrival order)
         if self.exchange == "kernel":
             from .xgmi import XgmiExchange
 
@@ -298,8 +302,8 @@ class PsSyncResidentTrainer(_BaseTrainer):
         with span("step"):
             if self.exchange == "kernel":
                 slot = self.engine.parity
-                self.engine.step_grad(batch_index, scale=1.0 / self.world, slot=slot)
-                self.xg.apply(self.params, self.lr, slot, self.global_step)
+                self.engine.step_grad(batch_index, scale=1.0 / (self.required or self.world), slot=slot)
+                self.xg.apply(self.params, self.lr, slot, self.global_step, required=self.required)
             else:
                 self.engine.step_xg(batch_index, 1.0 / self.world, self._xg_desc)
 
@@ -337,7 +341,10 @@ class PsSyncResidentTrainer(_BaseTrainer):
         how = ("exchange inside the backward launch over peer-mapped HBM" if self.exchange == "inbox" else
                "exchange as one bounded kernel after the backward (more workers share a GPU than can spin on it "
                "together) over peer-mapped HBM")
+        if self.required:
+            how = (f"exchange as one kernel after the backward over peer-mapped HBM, backup workers: the first "
+                   f"{self.required} gradients to arrive count")
         return (f"between-graph sync worker {self.rank} of {self.world}, device-resident: replica per worker, gradient "
-                f"{how} (mean of {self.world}, one update per "
+                f"{how} (mean of {self.required or self.world}, one update per "
                 f"{self.world} batches), {2 if self.exchange == 'inbox' else 3} launches/step"
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))

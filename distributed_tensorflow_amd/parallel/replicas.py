@@ -646,7 +646,7 @@ class XgmiTowerTrainer(_BaseTrainer):
     name = "xgmi"
 
     def __init__(self, *a, group=None, local_peers: bool = False, uncached_grads: bool = False,
-                 timeout_ms: int = 20000, **kw):
+                 timeout_ms: int = 20000, required: int = 0, **kw):
         kw["need_grads"] = False
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
@@ -655,6 +655,11 @@ class XgmiTowerTrainer(_BaseTrainer):
 
         if self.layout.var_range["global_step"][0] >= 4:
             raise RuntimeError("global_step must live in the first 16 bytes of the slab")
+        # backup replicas (SyncReplicasOptimizer with replicas_to_aggregate < total_num_replicas): an update is the
+        # mean of the first ``required`` gradients to arrive; 0 = every replica's
+        if not 0 <= int(required) <= self.world:
+            raise ValueError("required must lie in 0 .. world")
+        self.required = 0 if int(required) == self.world else int(required)
         self.xg = XgmiExchange(self.rank, self.world, self.params.numel(), self.device, group=group,
                                uncached_grads=uncached_grads, timeout_ms=timeout_ms, connect=not local_peers)
         self.engine.bind_grad_slots([self.layout.mlp_views(g) for g in self.xg.grads])
@@ -664,8 +669,8 @@ class XgmiTowerTrainer(_BaseTrainer):
         # The slot follows the engine's step parity: consecutive steps alternate between the two slabs,
         # which is what lets a peer still read step t's gradient while step t+1 is being computed.
         slot = self.engine.parity
-        self.engine.step_grad(batch_index, scale=1.0 / self.world, slot=slot)
-        self.xg.apply(self.params, self.lr, slot, self.global_step)
+        self.engine.step_grad(batch_index, scale=1.0 / (self.required or self.world), slot=slot)
+        self.xg.apply(self.params, self.lr, slot, self.global_step, required=self.required)
 
     def _capture(self, pos: int, n: int, parity: int):
         # Warm-up exchanges are real exchanges (every replica performs the same number of them) whose
@@ -695,8 +700,10 @@ class XgmiTowerTrainer(_BaseTrainer):
         self.xg.close()
 
     def describe(self):
+        what = (f"sum of {self.world} slabs" if not self.required else
+                f"sum of the first {self.required} of {self.world} slabs to arrive,")
         return (f"sync towers dp{self.world}: one-kernel gradient exchange over peer-mapped HBM "
-                f"(announce, wait, sum of {self.world} slabs in rank order, SGD apply), 3 launches/step"
+                f"(announce, wait, {what} in rank order, SGD apply), 3 launches/step"
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
 

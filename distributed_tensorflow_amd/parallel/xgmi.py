@@ -311,14 +311,27 @@ class XgmiExchange:
         self._flag_tab = u64(*self._peer_flag)
 
     # -- per step ----------------------------------------------------------------------
-    def apply(self, params: torch.Tensor, lr: torch.Tensor, slot: int, global_step: Optional[torch.Tensor] = None):
-        """``params -= lr * sum_r grads_r[slot]`` (+ ``global_step += 1``) on the current stream."""
+    def apply(self, params: torch.Tensor, lr: torch.Tensor, slot: int, global_step: Optional[torch.Tensor] = None,
+              required: int = 0):
+        """``params -= lr * sum_r grads_r[slot]`` (+ ``global_step += 1``) on the current stream.
+
+        ``required`` in 1 .. world - 1 (backup replicas, ``SyncReplicasOptimizer(replicas_to_aggregate < total)``): the
+        sum runs over the first ``required`` replicas to arrive in this exchange -- every replica must pass the same
+        number and scale its gradients by 1 / required; ``last_members()`` tells which ones counted."""
         if params.numel() != self.numel:
             raise ValueError("parameter slab and gradient slabs differ in size")
-        hb._check(hb.require().dtf_xgmi_allreduce_apply(
+        if not 0 <= int(required) <= self.world:
+            raise ValueError("required must lie in 0 .. world")
+        hb._check(hb.require().dtf_xgmi_allreduce_apply_subset(
             self._slot_tabs[int(slot) & 1], self._flag_tab, self._flag_ptr, params.data_ptr(), self.numel, lr.data_ptr(),
             None if global_step is None else global_step.data_ptr(), self.state.data_ptr(), self.rank, self.world,
-            self.timeout_ms, torch.cuda.current_stream(self.device).cuda_stream), "dtf_xgmi_allreduce_apply")
+            int(required), self.timeout_ms, torch.cuda.current_stream(self.device).cuda_stream),
+            "dtf_xgmi_allreduce_apply")
+
+    def last_members(self) -> List[int]:
+        """Ranks whose gradients counted in the last exchange with backup replicas (synchronises)."""
+        mask = int(self.state[3].item())
+        return [r for r in range(self.world) if (mask >> r) & 1]
 
     def failed(self) -> bool:
         """True once an exchange gave up waiting for a peer (reads the device word: synchronises)."""

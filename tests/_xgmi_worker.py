@@ -1,6 +1,6 @@
 """One replica of the peer-mapped exchange test (several of these share the GPU).
 
-usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|sync2c|async|async_sep]
+usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|sync2c|sync2p|sync_backup|async|async_sep]
 Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference
 (sync), or the state of the shared shards after every worker finished (async).
 """
@@ -56,17 +56,31 @@ def main():
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
     if mode in ("async", "async_sep"):
         return run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=mode == "async")
+    backup = mode == "sync_backup"          # the first world - 1 gradients of a step count (backup replicas)
+    extra = {} if mode in ("sync2", "sync2c", "sync2p") else {"uncached_grads": bool(uncached)}
+    if backup:
+        extra["required"] = world - 1
     t = build_replica_trainer({"sync2": "xgmi2", "sync2c": "xgmi2c", "sync2p": "xgmi2p"}.get(mode, "xgmi"), device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
-                              chunk=3, use_graph=bool(use_graph), timeout_ms=30000,
-                              **({} if mode in ("sync2", "sync2c", "sync2p") else {"uncached_grads": bool(uncached)}))
+                              chunk=3, use_graph=bool(use_graph), timeout_ms=30000, **extra)
     p0 = t.params.clone().cpu()
-    t.prepare((steps,))
-    dist.barrier()
-    t.run_steps(steps)
+    members = []
+    if backup and not use_graph:
+        import time
+
+        dist.barrier()
+        for s in range(steps):               # step by step: which replicas counted is read back after every exchange
+            if rank == (s % world):
+                time.sleep(0.02)             # a straggler per step (who is dropped is still up to the arrival order)
+            t.run_steps(1)
+            members.append(t.xg.last_members())
+    else:
+        t.prepare((steps,))
+        dist.barrier()
+        t.run_steps(steps)
     torch.cuda.synchronize()
     healthy = t.healthy()
     mine = {"params": t.params.cpu(), "x": ds.x_epoch.cpu(), "y": ds.y_epoch.cpu(), "sum": t.replica_checksum(),
-            "exchanges": t.xg.exchanges_done()}
+            "exchanges": t.xg.exchanges_done(), "members": members}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     identical = all(torch.equal(e["params"], everyone[0]["params"]) for e in everyone)
@@ -77,11 +91,14 @@ def main():
     views = lay.mlp_views(p)
     for s in range(steps):
         acc = {k: torch.zeros_like(v) for k, v in views.items()}
-        for e in everyone:
+        counted = members[s] if members else list(range(world))
+        for r, e in enumerate(everyone):
+            if r not in counted:
+                continue
             xb, yb = e["x"][s * B:(s + 1) * B], e["y"][s * B:(s + 1) * B]
             out = ref.mlp_grads(xb, yb, views["W1"], views["b1"], views["W2"], views["b2"])
             for k in acc:
-                acc[k] += out["d" + k] / world
+                acc[k] += out["d" + k] / len(counted)
         for k in views:
             views[k].sub_(acc[k], alpha=lr)
     err = float((mine["params"][4:] - p[4:]).abs().max())
@@ -92,7 +109,8 @@ def main():
     t.close()
     print(json.dumps({"rank": rank, "healthy": healthy, "identical": identical, "same_sum": same_sum,
                       "max_err": err, "scale": scale, "moved": moved, "global_step": gs,
-                      "exchanges": mine["exchanges"], "describe": t.describe()}), flush=True)
+                      "exchanges": mine["exchanges"], "describe": t.describe(), "members": members,
+                      "same_members": all(e["members"] == members for e in everyone)}), flush=True)
     dist.destroy_process_group()
 
 

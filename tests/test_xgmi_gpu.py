@@ -59,6 +59,28 @@ def test_replicas_stay_bit_identical_and_track_the_mean_gradient_reference(world
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,use_graph", [(3, False), (4, False), (3, True)])
+def test_backup_replicas_the_first_gradients_to_arrive_count_and_every_replica_applies_their_mean(world, use_graph):
+    """SyncReplicasOptimizer(replicas_to_aggregate = N - 1, total_num_replicas = N) on the one-kernel exchange
+    (tfdist_between_sync.py:66-67 passes equal values, the optimizer takes fewer): every exchange sums N - 1 of the N
+    gradient slabs -- the arrival order decides, one ticket word, all replicas read the same verdict -- and every replica,
+    the dropped one included, applies that mean.  Eager: the members of every step are read back and the CPU oracle
+    averages exactly those; captured chunks: health, bit-identity and the step count."""
+    steps = 7
+    results = _run_replicas(world, steps, use_graph, mode="sync_backup")
+    for r in results:
+        assert r["healthy"], r
+        assert r["identical"] and r["same_sum"], r
+        assert r["global_step"] == steps and r["moved"] > 1e-3
+        assert "first %d of %d" % (world - 1, world) in r["describe"]
+        if not use_graph:
+            assert r["same_members"] and len(r["members"]) == steps
+            assert all(len(m) == world - 1 and len(set(m)) == world - 1 for m in r["members"]), r["members"]
+            assert r["max_err"] <= 2e-5 * max(1.0, r["scale"]), r
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("world,use_graph,mode", [(2, False, "async"), (3, True, "async"), (4, True, "async"),
                                                   (2, True, "async_sep")])
 def test_async_workers_update_shared_shards_one_sidedly(world, use_graph, mode):
