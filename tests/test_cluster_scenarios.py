@@ -54,6 +54,19 @@ def test_readme_scenario(script, n_ps, n_w, tmp_path):
 
 
 @pytest.mark.slow
+def test_sync_script_with_a_backup_worker(tmp_path):
+    """tfdist_between_sync.py --replicas_to_aggregate=2 with three workers: SyncReplicasOptimizer with fewer gradients
+    per update than replicas (the reference passes equal values, tfdist_between_sync.py:66-67): an update takes the
+    first two gradients of a step, the third is dropped as stale, every worker gets a token -- one update per round."""
+    res = launch_script("tfdist_between_sync.py", 1, 3, ARGS + ["--replicas_to_aggregate=2", f"--logs_path={tmp_path}"])
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    finals = [_check_worker(res[f"worker{i}"][1])[0][-1] for i in range(3)]
+    # 11 rounds of three workers; a worker whose last gradient was the dropped one may print one step more or less
+    assert all(10 <= f <= 12 for f in finals), finals
+
+
+@pytest.mark.slow
 def test_async_workers_on_the_device_resident_tier(tmp_path):
     """--resident: no per-batch feed; pull, gradient kernels and push per step against the PS shards."""
     res = launch_script("tfdist_between.py", 2, 2, ARGS[:-1] + ["--resident", f"--logs_path={tmp_path}"])

@@ -222,6 +222,36 @@ def test_resident_sync_workers_of_a_deeper_stack_stay_identical(n_ps, n_w, trans
     assert all(c[-1] < c[0] for c in costs)
 
 
+@pytest.mark.parametrize("hidden", [None, "64,32"])
+def test_resident_sync_workers_with_a_backup_worker(hidden, tmp_path):
+    """tfdist_between_sync.py --resident --replicas_to_aggregate=2 with three workers (SyncReplicasOptimizer with
+    replicas_to_aggregate < total_num_replicas; the reference passes equal values, tfdist_between_sync.py:66-67): an
+    update is the mean of the first two gradients to arrive, decided inside the exchange kernel; all three workers apply
+    it, stay bit-identical and in lock step.  The reference's network and a deeper stack."""
+    import re
+
+    from cluster_utils import launch_script
+
+    args = ["--epochs=2", "--train_size=2200", "--freq=11", "--lr=0.02", "--transport=ipc", "--resident",
+            "--replicas_to_aggregate=2", f"--logs_path={tmp_path}"]
+    if hidden:
+        args += [f"--hidden={hidden}", "--activation=relu"]
+    res = launch_script("tfdist_between_sync.py", 1, 3, args, timeout=200)
+    for name, (rc, out) in res.items():
+        assert rc == 0, f"{name} exited {rc}:\n{out[-3000:]}"
+    steps, costs, accs = [], [], []
+    for i in range(3):
+        out = res[f"worker{i}"][1]
+        assert "first 2" in out and "hipGraph chunks" in out, out[-2000:]
+        assert out.rstrip().endswith("Done")
+        steps.append([int(v) for v in re.findall(r"Step: (\d+),", out)])
+        costs.append([float(c) for c in re.findall(r"Cost: ([\d.]+)", out)])
+        accs.append(re.findall(r"Test-Accuracy: ([\d.]+)", out))
+    assert all(s == steps[0] for s in steps) and steps[0][-1] == 2 * 22     # one update per round of the three workers
+    assert all(a == accs[0] for a in accs) and len(accs[0]) == 2            # bit-identical replicas evaluate identically
+    assert all(c[-1] < c[0] for c in costs)
+
+
 def test_checkpoints_during_a_resident_sync_run_save_the_replica_and_leave_it_alone(tmp_path):
     """tfdist_between_sync.py --resident --hidden 64,32 with a checkpoint every 0.2 s: while the trainer is attached
     the parameter-server shards still hold the initial values, so a save that pulled them would write a stale
