@@ -10,7 +10,11 @@ chief saves; the shards are gathered to the chief through a normal pull.
 The bundle is written by the native writer (runtime/records.cpp).  Byte-level
 interchange with TensorFlow's reader is not verified here (TensorFlow is not
 installable in this environment) — "parity unpinned"; layout, naming, CRCs and
-round-tripping through :func:`read_bundle` are tested.
+round-tripping through :func:`read_bundle` are tested, and the FORMAT is checked
+by a decoder that shares no code with this package: the table of the ``.index``
+file taken apart by hand, its ``BundleHeaderProto`` / ``BundleEntryProto`` values
+parsed by Google's protobuf runtime under TensorFlow's field numbers
+(tests/test_saver_supervisor_summary.py).
 """
 from __future__ import annotations
 
