@@ -454,7 +454,9 @@ class PsDenseSyncResidentTrainer:
     from step to step) and ONE exchange kernel that waits for every worker's slab of that step, sums them in rank order
     through HIP-IPC mappings and applies SGD to the local replica (``xgmi.XgmiExchange``: a bounded grid, so any number
     of workers can share a GPU).  The handles travel through the control store of ps task 0; the replicas stay
-    bit-identical; ``publish()`` copies the chief's replica back into the PS shards.  Workers must share a node."""
+    bit-identical; ``publish()`` copies the chief's replica back into the PS shards.  Workers must share a node.
+    Backup workers (``replicas_to_aggregate = R < total_num_replicas``): the exchange kernel averages the first R
+    gradients to arrive (arrival tickets, ``csrc/xgmi.hip``) and every worker applies that mean."""
 
     name = "ps-dense-sync-resident"
 

@@ -222,6 +222,10 @@ class PsSyncResidentTrainer(_BaseTrainer):
     share no ``torch.distributed`` group — and a step is the two-launch cross-replica step of
     ``MLPEngine.step_xg``.  The replicas stay bit-identical; ``publish()`` (the chief calls it at the end of the
     run and before a checkpoint) copies them back into the PS shards.  The workers must share a node.
+
+    Backup workers (``replicas_to_aggregate = R < total_num_replicas``): a step becomes the gradient launches plus the
+    one-kernel exchange in its form with arrival tickets (``csrc/xgmi.hip``: the first R gradients to arrive are
+    averaged, every worker applies that mean).  Every worker still takes part in every step -- it keeps a replica.
     """
 
     name = "ps-sync-resident"
