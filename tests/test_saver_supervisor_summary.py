@@ -181,12 +181,22 @@ def _tf_event_classes():
     event.field.add(name="file_version", number=3, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
     event.field.add(name="graph_def", number=4, type=F.TYPE_BYTES, label=F.LABEL_OPTIONAL)
     event.field.add(name="summary", number=5, type=F.TYPE_MESSAGE, label=F.LABEL_OPTIONAL, type_name=".dtftest.Summary")
+    # core/framework/graph.proto + node_def.proto, the fields the graph tab reads
+    node = fd.message_type.add(name="NodeDef")
+    node.field.add(name="name", number=1, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    node.field.add(name="op", number=2, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    node.field.add(name="input", number=3, type=F.TYPE_STRING, label=F.LABEL_REPEATED)
+    node.field.add(name="device", number=4, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    graph = fd.message_type.add(name="GraphDef")
+    graph.field.add(name="node", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".dtftest.NodeDef")
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = getattr(message_factory, "GetMessageClass", None)
     if get is None:      # older protobuf runtimes
-        return message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("dtftest.Event"))
-    return get(pool.FindMessageTypeByName("dtftest.Event"))
+        get = message_factory.MessageFactory(pool).GetPrototype
+    event_cls = get(pool.FindMessageTypeByName("dtftest.Event"))
+    event_cls.GraphDef = get(pool.FindMessageTypeByName("dtftest.GraphDef"))
+    return event_cls
 
 
 def _crc32c(data: bytes) -> int:
@@ -239,7 +249,15 @@ def test_event_file_is_a_tfrecord_stream_of_event_protos_for_an_independent_deco
         pos += 12 + length + 4
     assert pos == len(blob)
     assert events[0].file_version == "brain.Event:2" and events[0].wall_time > 1e9
-    assert any(len(e.graph_def) > 0 for e in events)
+    graphs = [e.graph_def for e in events if len(e.graph_def)]
+    assert len(graphs) == 1
+    gd = Event.GraphDef()
+    gd.ParseFromString(graphs[0])                      # what TensorBoard's graph tab reads (tfsingle.py:63)
+    nodes = {n.name: n for n in gd.node}
+    assert {"weights/Variable", "weights/Variable_1", "biases/Variable", "biases/Variable_1", "global_step",
+            "input/x-input", "input/y-input"} <= set(nodes)
+    assert nodes["input/x-input"].op == "Placeholder" and nodes["weights/Variable"].op.startswith("Variable")
+    assert all(i.split(":")[0].lstrip("^") in nodes for n in gd.node for i in n.input)     # every edge has both ends
     scal = [e for e in events if len(e.summary.value)]
     assert [e.step for e in scal] == [0, 1, 2]
     for e, c in zip(scal, costs):
