@@ -113,12 +113,19 @@ def synthetic_mnist_hard(n: int, seed: int, proto_seed: int = 1234) -> Tuple[np.
 
 
 def _read_idx(path: str) -> np.ndarray:
+    """An idx file of unsigned bytes (the MNIST distribution's format: two zero bytes, the element type 0x08, the
+    number of dimensions, the big-endian sizes, the data), plain or gzip-compressed."""
     opener = gzip.open if path.endswith(".gz") else open
     with opener(path, "rb") as f:
-        magic = struct.unpack(">I", f.read(4))[0]
-        ndim = magic & 0xFF
+        head = f.read(4)
+        if len(head) != 4 or head[0] != 0 or head[1] != 0 or head[2] != 0x08 or not 1 <= head[3] <= 4:
+            raise ValueError(f"{path}: not an idx file of unsigned bytes (header {head.hex()})")
+        ndim = head[3]
         dims = struct.unpack(">" + "I" * ndim, f.read(4 * ndim))
-        return np.frombuffer(f.read(), dtype=np.uint8).reshape(dims)
+        data = np.frombuffer(f.read(), dtype=np.uint8)
+        if data.size != int(np.prod(dims, dtype=np.int64)):
+            raise ValueError(f"{path}: {data.size} bytes of data for dimensions {dims}")
+        return data.reshape(dims)
 
 
 def _find_idx(data_dir: str, stem: str) -> Optional[str]:

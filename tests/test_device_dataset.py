@@ -1,5 +1,6 @@
 """DeviceDataset on the CPU: epoch reshuffles, staged permutations, Gram blocks of consecutive mini-batches."""
 import numpy as np
+import pytest
 import torch
 
 from distributed_tensorflow_amd.data import DeviceDataset
@@ -117,3 +118,55 @@ def test_next_batch_orders_are_those_of_a_fresh_images_perm_per_epoch():
                 want_x, want_y = xi[pos:pos + batch], yi[pos:pos + batch]
                 pos += batch
             assert np.array_equal(bx, want_x) and np.array_equal(by, want_y)
+
+
+def _write_idx(path, array):
+    import gzip
+    import struct
+
+    array = np.ascontiguousarray(array, dtype=np.uint8)
+    blob = bytes([0, 0, 0x08, array.ndim]) + struct.pack(">" + "I" * array.ndim, *array.shape) + array.tobytes()
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            f.write(blob)
+    else:
+        with open(path, "wb") as f:
+            f.write(blob)
+
+
+def test_read_data_sets_reads_the_mnist_idx_files_the_reference_would_download(tmp_path):
+    """``input_data.read_data_sets("MNIST_data", one_hot=True)`` (tfsingle.py:6-7): with the four idx files of the MNIST
+    distribution in the directory (gzip-compressed or not) they ARE the data -- 55,000 training rows after the first 5,000
+    of the training file became the validation split, 10,000 test rows, pixels scaled to [0, 1], one-hot labels.
+    (Files of the distribution's format and sizes written here: there is no network to fetch the real ones.)"""
+    from distributed_tensorflow_amd.data import mnist as M
+
+    rng = np.random.RandomState(3)
+    tr_l = rng.randint(0, 10, 60000)
+    te_l = rng.randint(0, 10, 10000)
+    tr_i = np.zeros((60000, 28, 28), np.uint8)
+    te_i = np.zeros((10000, 28, 28), np.uint8)
+    tr_i[np.arange(60000), tr_l, tr_l] = 255                      # one bright pixel that tells the label
+    tr_i[:, 27, 27] = (np.arange(60000) % 256).astype(np.uint8)   # ... and one that tells the row
+    te_i[np.arange(10000), te_l, te_l] = 128
+    _write_idx(tmp_path / "train-images-idx3-ubyte.gz", tr_i)
+    _write_idx(tmp_path / "train-labels-idx1-ubyte.gz", tr_l)
+    _write_idx(tmp_path / "t10k-images-idx3-ubyte", te_i)         # (uncompressed files are found as well)
+    _write_idx(tmp_path / "t10k-labels-idx1-ubyte", te_l)
+    d = M.read_data_sets(str(tmp_path), one_hot=True)
+    assert d.source == "mnist-idx"
+    assert d.train.images.shape == (55000, 784) and d.validation.images.shape == (5000, 784)
+    assert d.test.images.shape == (10000, 784) and d.train.labels.shape == (55000, 10)
+    assert d.train.images.dtype == np.float32 and float(d.train.images.max()) == 1.0
+    np.testing.assert_array_equal(d.validation.labels.argmax(1), tr_l[:5000])
+    np.testing.assert_array_equal(d.train.labels.argmax(1), tr_l[5000:])
+    np.testing.assert_array_equal(d.test.labels.argmax(1), te_l)
+    row = 5000 + 123                                              # training row 123 is row 5123 of the file
+    np.testing.assert_allclose(d.train.images[123, 27 * 28 + 27], (row % 256) / 255.0, rtol=1e-6)
+    np.testing.assert_allclose(d.test.images[7, te_l[7] * 28 + te_l[7]], 128 / 255.0, rtol=1e-6)
+    xb, yb = d.train.next_batch(100)
+    assert xb.shape == (100, 784) and yb.shape == (100, 10) and np.all(yb.sum(1) == 1)
+    # a file that is not an idx file of bytes is refused, not reshaped
+    (tmp_path / "t10k-labels-idx1-ubyte").write_bytes(b"\\x00\\x00\\x0d\\x01" + b"\\x00" * 100)
+    with pytest.raises(ValueError, match="idx"):
+        M.read_data_sets(str(tmp_path), one_hot=True)
