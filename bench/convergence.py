@@ -9,8 +9,8 @@ Tiers: ``oracle`` plain PyTorch ops (autograd-free closed form, ops/reference.py
 ``single`` the one-launch pipelined step; ``two_launch`` the fused two-launch step; ``async`` one asynchronous
 worker against a GPU-resident shard (one-sided pull / push in the backward); ``towers`` synchronous replicas of
 one (gradient slab + sharded SGD kernel); ``cluster`` the between-graph scripts as separate processes
-(``--resident``, ipc transport): 1 ps + 2 asynchronous workers (110,000 updates) and 1 ps + 2 synchronous
-workers (55,000 updates).  Prints one line per checkpoint and a JSON summary.
+(``--resident``, ipc transport): 1 ps + 2 asynchronous workers (110,000 updates), 1 ps + 2 synchronous workers (55,000
+updates), 1 ps + 3 asynchronous workers (165,000 updates), 1 ps + 3 synchronous workers with a backup worker (55,000).  Prints one line per checkpoint and a JSON summary.
 """
 import argparse
 import json
@@ -71,10 +71,10 @@ def trainer_curve(mode, mnist, dev, epochs, checkpoints, **kw):
     return out
 
 
-def cluster_final(script, workers, epochs, variant):
+def cluster_final(script, workers, epochs, variant, extra=()):
     env = dict(os.environ, DTF_DATA_VARIANT=variant)
     cmd = [sys.executable, os.path.join(ROOT, "bench", "run_cluster.py"), "--script", script, "--ps", "1", "--workers",
-           str(workers), "--transport", "ipc", "--epochs", str(epochs), "--timeout", "900", "--", "--resident"]
+           str(workers), "--transport", "ipc", "--epochs", str(epochs), "--timeout", "900", "--", "--resident", *extra]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1000)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if not line:
@@ -109,6 +109,11 @@ def main():
         elif tier == "cluster" and dev.type == "cuda":
             table["cluster_async_1ps_2w_100_epochs"] = cluster_final("tfdist_between.py", 2, 100, args.variant)
             table["cluster_sync_1ps_2w_100_epochs"] = cluster_final("tfdist_between_sync.py", 2, 100, args.variant)
+            # the reference's last recipe (README.md:231-254 there): three asynchronous workers, 165,000 updates
+            table["cluster_async_1ps_3w_100_epochs"] = cluster_final("tfdist_between.py", 3, 100, args.variant)
+            # three synchronous workers of which the first two gradients of a step count (a backup worker): 55,000 updates
+            table["cluster_sync_1ps_3w_backup_100_epochs"] = cluster_final("tfdist_between_sync.py", 3, 100, args.variant,
+                                                                           ("--replicas_to_aggregate=2",))
         else:
             continue
         print(f"{tier:>11}: {table.get(tier, '')}  ({time.time() - t0:.1f}s)", flush=True)
