@@ -316,10 +316,11 @@ class IpcVariableStore:
             else:
                 hb.sgd_apply_(p, grads[a:b], lr_t, 1.0, False, gs)
 
-    def push_descriptor(self, offsets: dict, bump_step: bool = True) -> "hb.DtfXgDesc":
+    def push_descriptor(self, offsets: dict, bump_step: bool = True, read_shards: bool = False) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_async`` for these shards: the backward launch itself applies ``-lr * g`` of
         every gradient element to the shard that holds the variable (lock-free; tfdist_between.py:65-66).
-        ``offsets`` maps W1 / b1 / W2 / b2 to their element offsets in the local slab."""
+        ``offsets`` maps W1 / b1 / W2 / b2 to their element offsets in the local slab.  ``read_shards``: the step's
+        forward reads the variables from the mapped shards themselves -- no ``pull`` in front of the step."""
         if self.n > hb.require().dtf_xgmi_max_ranks():
             raise ValueError("more parameter-server shards than the step's shard table holds")
         d = hb.DtfXgDesc()
@@ -333,6 +334,7 @@ class IpcVariableStore:
         d.offW1, d.offb1, d.offW2, d.offb2 = (int(offsets[k]) for k in ("W1", "b1", "W2", "b2"))
         d.rank, d.world, d.timeout_ms = self.widx, self.n, 0
         d.step_index = self.layout.var_range["global_step"][0] if (bump_step and "global_step" in self.layout.var_range) else -1
+        d.compact = 1 if read_shards else 0
         return d
 
     # -- SyncReplicas protocol ------------------------------------------------------------------
