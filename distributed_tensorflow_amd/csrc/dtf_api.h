@@ -161,7 +161,9 @@ typedef struct DtfXgDesc {
   uint64_t inbox[DTF_XGMI_MAX_RANKS];   // device address of every rank's inbox: 2 slots (even / odd exchange
                                         //   numbers) of 8-byte words [source rank * n + element], uncached
                                         //   memory, zero-initialised
-  uint32_t* state;                      // 4 zero-initialised words in local memory
+  uint32_t* state;                      // dtf_mlp_step_xg: 4 zero-initialised words in local memory; dtf_mlp_step_async:
+                                        //   null, or one word that receives global_step (a float) as it was before this
+                                        //   step's push
   int64_t n;                            // elements per source row
   int64_t offW1, offb1, offW2, offb2;   // element offsets of the gradients inside a row
   int32_t rank, world, timeout_ms;

@@ -1272,7 +1272,20 @@ __device__ __forceinline__ void bwd_tile16_body(const BwdParams& p, float* smem,
     const XgParams& x = *xg;
     if (xv[0]) xa_push(x, xe[0], -lr * xown[0]);
     if (xv[1]) xa_push(x, xe[1], -lr * xown[1]);
-    if (stats_block && tid == 0 && x.step_index >= 0) xa_push(x, x.step_index, 1.0f);
+    if (stats_block && tid == 0 && x.step_index >= 0) {
+      if (x.state == nullptr) {
+        xa_push(x, x.step_index, 1.0f);
+      } else {
+        // the caller wants the counter as it was before this push (a per-batch session's fetch of global_step next to
+        // the train op, tfdist_between.py:94): the atomic's return value, instead of a read and a copy of its own
+        uint64_t* base = x.inbox[0];
+#pragma unroll
+        for (int k = 1; k < DTF_XGMI_MAX_RANKS; ++k) base = ((unsigned)x.step_index >= x.start[k]) ? x.inbox[k] : base;
+        const float before = __hip_atomic_fetch_add(reinterpret_cast<float*>(base) + x.step_index, 1.0f, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM);
+        *reinterpret_cast<float*>(x.state) = before;
+      }
+    }
   }
   if constexpr (XW > 0) {
     const XgParams& x = *xg;
@@ -1824,7 +1837,7 @@ extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int pari
   if (x->step_index >= total || x->offW1 < 0 || x->offW1 + K * H > total || x->offb1 < 0 ||
       x->offb1 + H > total || x->offW2 < 0 || x->offW2 + H * C > total || x->offb2 < 0 || x->offb2 + C > total)
     return DTF_ERR_SHAPE;
-  a.state = nullptr;
+  a.state = x->state;       // asynchronous step: null, or ONE word that receives global_step as it was before this push
   a.n = 0;
   a.slot_words = 0;
   a.offW1 = x->offW1; a.offb1 = x->offb1; a.offW2 = x->offW2; a.offb2 = x->offb2;

@@ -368,6 +368,9 @@ def run_worker(server, cluster, flags, sync: bool) -> dict:
             sv.request_stop()
         result["global_step"] = sess.store.global_step()
         result["fused_steps"] = sess.fused_steps
+        if sess.fused_steps or sess.generic_steps:
+            print(f"[session] per-batch steps: {sess.fused_steps} on the fused kernels ({sess.pushed_steps} of them pushed "
+                  f"their update from the backward launch), {sess.generic_steps} generic", flush=True)
     sv.stop()
     print("Done")
     return result

@@ -316,6 +316,10 @@ class IpcVariableStore:
             else:
                 hb.sgd_apply_(p, grads[a:b], lr_t, 1.0, False, gs)
 
+    def step_counter_view(self) -> torch.Tensor:
+        """The live ``global_step`` element in its owner's shard (one float of mapped device memory)."""
+        return self._params(self._gs_shard)[self._gs_off:self._gs_off + 1]
+
     def push_descriptor(self, offsets: dict, bump_step: bool = True, read_shards: bool = False) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_async`` for these shards: the backward launch itself applies ``-lr * g`` of
         every gradient element to the shard that holds the variable (lock-free; tfdist_between.py:65-66).

@@ -219,6 +219,7 @@ class Session:
         self.fused_steps = 0
         self._local_step_ready = False
         self.generic_steps = 0
+        self.pushed_steps = 0       # fused steps of an asynchronous worker whose backward launch pushed the update itself
         self.dense_steps = 0        # steps of fully connected stacks other than the reference's (models/dense.py)
         # host mirror of global_step for a local session (None: unknown, re-read from the device): saves one
         # blocking device-to-host copy per sess.run that fetches it next to a train op
@@ -362,7 +363,8 @@ class Session:
             feed[k] = v
         cache: Dict[G.Tensor, Any] = {}
         needs_vars = any(self._reads_variables(f) for f in flist if isinstance(f, G.Tensor))
-        if needs_vars and self.store.is_remote:
+        shard_step = self._fused_async_call(flist, feed) if (needs_vars and self.store.is_remote) else None
+        if needs_vars and self.store.is_remote and shard_step is None:
             self._pull()
         # train ops first: they define the forward pass the other fetches see.  Variables fetched
         # in the same call (global_step) are read BEFORE the update — the reference prints
@@ -378,6 +380,11 @@ class Session:
                         if self._gs_mirror is None:
                             self._gs_mirror = int(round(float(self._var_view(f).item())))
                         cache[f] = torch.tensor(float(self._gs_mirror))         # host value, pre-update
+                    elif shard_step is not None and f is gs_var:
+                        # a call served by the fused asynchronous step has no pull in front, and the step itself hands
+                        # back the counter as it was before its push (the reference's fetch next to the train op reads
+                        # it unordered, tfdist_between.py:94,102): _run_train puts it into the cache
+                        pass
                     else:
                         view = self._var_view(f)
                         if self._host_words is not None and view.numel() == 1 and not pending_used:
@@ -578,7 +585,8 @@ class Session:
             grads = {r: self.layout.view(self.grad, n) for r, n in names.items()}
             eng = MLPEngine(params, grads, batch=batch, lr=0.0, act=m["act"], hist_cap=1)
             # loss and batch accuracy side by side: ONE 8-byte device-to-host copy per step
-            eng._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+            # ([2]: the step counter before the push of a fused asynchronous step, see _async_descriptor)
+            eng._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
             eng.loss_hist, eng.acc_hist = eng._stats[0:1], eng._stats[1:2]
             K, C = params["W1"].shape[0], params["W2"].shape[1]
             # the fed batch travels as ONE host-to-device copy: x and y side by side in a pinned host buffer
@@ -659,6 +667,80 @@ class Session:
             self._plans[id(train_op)] = plan
         return plan
 
+    def _async_descriptor(self, train_op, eng: MLPEngine, m):
+        """The shard table of the fused asynchronous step (``MLPEngine.step_async`` with a forward that reads the
+        variables from the mapped shards and a backward that pushes ``-lr * g`` per element: 2 launches, no pull, no
+        separate apply), or None when this train op / store / model does not qualify.  Decided once per engine."""
+        desc = getattr(eng, "_async_desc", False)
+        if desc is not False:
+            return desc
+        desc = None
+        opt = train_op.attrs["optimizer"]
+        if (self.device.type == "cuda" and hasattr(self.store, "push_descriptor") and not isinstance(opt, SyncReplicasOptimizer)
+                and not opt.use_locking and os.environ.get("DTF_ASYNC_FUSED_PER_BATCH", "1") != "0"):
+            names = {r: m[r].op_name for r in ("W1", "b1", "W2", "b2")}
+            trainable = {s.name for s in self.layout.specs if s.trainable}
+            if trainable == set(names.values()):
+                from .ops import hip_backend as hb
+
+                offs = {r: self.layout.var_range[n][0] for r, n in names.items()}
+                try:
+                    desc = self.store.push_descriptor(offs, bump_step=train_op.attrs["global_step"] is not None,
+                                                      read_shards=True)
+                    desc.state = eng._stats[2:3].data_ptr()      # receives global_step as it was before the step's push
+                    keep = eng.lr.clone()
+                    eng.lr.zero_()                       # loads the kernels and checks the shard table: adds zero, no count
+                    eng.step_async(0, self.store.push_descriptor(offs, bump_step=False, read_shards=True))
+                    eng.lr.copy_(keep)
+                    eng.reset_step_workspace(0)
+                except (ValueError, hb.HipKernelError):
+                    desc = None
+        eng._async_desc = desc
+        return desc
+
+    def _fused_async_call(self, flist, feed):
+        """For a ``sess.run`` of ONE asynchronous train op of the fused model on mapped shards whose other fetches are
+        served by the step itself (cost, accuracy, summaries of them) or are its step counter: the counter's element in
+        its owner's shard -- such a call needs no pull (True).  None: pull as usual."""
+        trains = [f for f in flist if _is(f, "train")]
+        if len(trains) != 1 or not hasattr(self.store, "push_descriptor"):
+            return None
+        train_op = trains[0]
+        plan = self._plan(train_op)
+        m = plan["mlp"]
+        if m is None or m["x"] not in feed or m["y_"] not in feed:
+            return None
+        gs_var = train_op.attrs["global_step"]
+        for f in flist:
+            if f is train_op or f is None:
+                continue
+            if _is(f, "variable"):
+                if f is not gs_var:
+                    return None
+            elif not self._served_by_step(f, m, plan):
+                return None
+        opt = train_op.attrs["optimizer"]
+        if isinstance(opt, SyncReplicasOptimizer) or opt.use_locking:
+            return None
+        if not self._local_step_ready:           # (the shards are allocated and mapped before the first view of them)
+            self.store.sync_local_step()
+            self._local_step_ready = True
+        eng = self._engine_for(m, int(feed[m["x"]].shape[0]))
+        if self._async_descriptor(train_op, eng, m) is None:
+            return None
+        return True
+
+    def _served_by_step(self, f, m, plan, _depth: int = 0) -> bool:
+        """True when ``f`` is computed from the fused step's own results (its loss, its batch accuracy, summaries of
+        them) without reading a variable."""
+        if not isinstance(f, G.Tensor) or _depth > 8:
+            return False
+        if f is m["loss"] or f in plan["acc_nodes"]:
+            return True
+        if f.op in ("scalar_summary", "merge_summary"):
+            return all(self._served_by_step(i, m, plan, _depth + 1) for i in f.inputs)
+        return False
+
     def _run_train(self, train_op, feed, cache):
         opt: Optimizer = train_op.attrs["optimizer"]
         plan = self._plan(train_op)
@@ -682,10 +764,22 @@ class Session:
                     # the backward kernel writes this step's gradient straight into the worker's mailbox row
                     eng.step_grad(0, 1.0, slot=self.store.next_mailbox_slot())
                     applied = "deposited"
+                elif not sync and self._async_descriptor(train_op, eng, m) is not None:
+                    # asynchronous worker on mapped shards: the forward reads the variables from the shards, the
+                    # backward pushes -lr * g per element and counts the step (no pull, no separate apply)
+                    if getattr(eng, "_async_lr", None) != lr:
+                        eng.set_lr(lr)
+                        eng._async_lr = lr
+                    eng.step_async(0, eng._async_desc)
+                    applied = "pushed"
+                    self.pushed_steps += 1
                 else:
                     eng.step_grad(0, 1.0)
             with span("fetch_stats"):
-                host = self._stats_to_host(eng._stats)          # the step's only wait for the device
+                # the step's only wait for the device
+                host = self._stats_to_host(eng._stats[:3] if applied == "pushed" else eng._stats[:2])
+            if applied == "pushed" and train_op.attrs["global_step"] is not None:
+                cache[train_op.attrs["global_step"]] = host[2]
             cache[m["loss"]] = host[0]
             cache[("acc", id(m["loss"]))] = host[1]
             for n in plan["acc_nodes"]:
@@ -764,11 +858,12 @@ class Session:
         """The two statistics of a fused step on the host; waits for the step."""
         if self._host_words is None or stats.device.type != "cuda":
             return stats.cpu()
+        n = stats.numel()            # 2, or 3 with the step counter of a fused asynchronous step
         with torch.cuda.device(self.device):
-            self._host_words[0:2].copy_(stats, non_blocking=True)
+            self._host_words[0:n].copy_(stats, non_blocking=True)
             self._host_evt.record()
         self._host_evt.synchronize()
-        return self._host_words[0:2].clone()
+        return self._host_words[0:n].clone()
 
     def _mailbox_gradients(self, eng: MLPEngine, m) -> bool:
         """Synchronous replicas on a transport with GPU-resident mailboxes: let the engine write its gradients INTO

@@ -114,6 +114,10 @@ def test_ipc_transport_gpu_resident_shards(script, n_ps, n_w, board, tmp_path):
         assert finals == [11] * n_w
     else:
         assert 11 * n_w - (n_w - 1) <= max(finals) <= 11 * n_w
+        # asynchronous workers on mapped shards: forward that reads the variables from the shards, backward that pushes
+        # (two launches per sess.run, no pull, no separate apply; the step counter comes back from the push itself)
+        for i in range(n_w):
+            assert "11 on the fused kernels (11 of them pushed" in res[f"worker{i}"][1]
 
 
 @pytest.mark.parametrize("n_ps,n_w", [(1, 1), (2, 2)])
