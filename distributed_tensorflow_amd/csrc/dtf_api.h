@@ -184,6 +184,11 @@ typedef struct DtfXgDesc {
 // mappings and counts the push.  n > 0: equal shards of n floats, inbox[k] = base of rank k's slab-sized buffer;
 // n == 0: shard k = slab elements [shard_start[k], shard_start[k+1]), inbox[k] = address of its first element.
 int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream);
+// Gradient step of a worker whose variables live in shards it has mapped: the forward reads them from the shards (no
+// pull in front), the backward writes grad_scale * gradient to d->gW1 .. d->gb2.  x: the shard table as above (state,
+// step_index and compact are not used).
+int dtf_mlp_step_grad_shards(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
+                             void* stream);
 int dtf_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 int dtf_mlp_step_xg(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale, const DtfXgDesc* x,
                     void* stream);

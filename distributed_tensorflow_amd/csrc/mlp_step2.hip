@@ -1801,13 +1801,11 @@ static int launch_step2_impl(const DtfMlpDesc* d, long batch_index, int parity, 
 // x->n > 0: `world` equal shards of n floats, x->inbox[k] = base of rank k's slab-sized buffer;
 // x->n == 0: shard k holds slab elements [shard_start[k], shard_start[k+1]) and x->inbox[k] is the address of ITS
 // first element (shards of different sizes, e.g. whole variables dealt over parameter-server tasks).
-extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream) {
-  if (!d || !x) return DTF_ERR_NULL;
-  if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
+// The shard table of a step that works on parameter-server shards directly: a.inbox / a.start (where an element's
+// owner keeps it) and, for a forward that reads the variables from the shards, the same as a ShardView.
+static int shard_tables(const DtfMlpDesc* d, const DtfXgDesc* x, XgParams& a, ShardView& sv, bool want_view) {
   if (x->world < 1 || x->world > DTF_XGMI_MAX_RANKS || x->n < 0 || (x->n & 3)) return DTF_ERR_SHAPE;
-  if (!d->gW1 || !d->gb1 || !d->gW2 || !d->gb2) return DTF_ERR_NULL;     // valid (unused) gradient locations
   const long K = d->in_dim, H = d->hidden, C = d->classes;
-  XgParams a;
   long total = 0;
   for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
     a.inbox[r] = nullptr;
@@ -1846,10 +1844,7 @@ extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int pari
   a.world = x->world;
   a.compact = 0;
   a.timeout_ticks = 0;
-  if (x->compact != 1)
-    return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true);
-  // x->compact == 1 here means: no pull in front of this step -- the forward reads the variables from the shards.
-  ShardView sv;
+  if (!want_view) return DTF_OK;
   for (int r = 0; r < DTF_XGMI_MAX_RANKS; ++r) {
     sv.base[r] = reinterpret_cast<const float*>(a.inbox[r]);
     sv.start[r] = a.start[r];
@@ -1860,22 +1855,49 @@ extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int pari
   sv.offW1 = (unsigned)x->offW1; sv.offb1 = (unsigned)x->offb1; sv.offW2 = (unsigned)x->offW2; sv.offb2 = (unsigned)x->offb2;
   // A wave's range of W1 (32 rows of a column tile), a tile's bias and W2 elements must meet at most one shard
   // boundary: every boundary inside the variables is followed by a shard of at least 32 rows of W1.
-  {
-    const long lo = x->offW1 < x->offW2 ? (x->offW1 < x->offb1 ? x->offW1 : x->offb1) : (x->offW2 < x->offb1 ? x->offW2 : x->offb1);
-    long hi = x->offW1 + K * H;
-    if (x->offb1 + H > hi) hi = x->offb1 + H;
-    if (x->offW2 + H * C > hi) hi = x->offW2 + H * C;
-    if (x->offb2 + C > hi) hi = x->offb2 + C;
-    long bounds[DTF_XGMI_MAX_RANKS + 1];
-    int nb = 0;
-    for (int r = 1; r < x->world; ++r) {
-      const long st = a.start[r];
-      if (st > lo && st < hi && (nb == 0 || bounds[nb - 1] != st)) bounds[nb++] = st;
-    }
-    for (int i = 0; i + 1 < nb; ++i)
-      if (bounds[i + 1] - bounds[i] < 32 * H + 16) return DTF_ERR_UNSUPPORTED;
+  const long lo = x->offW1 < x->offW2 ? (x->offW1 < x->offb1 ? x->offW1 : x->offb1) : (x->offW2 < x->offb1 ? x->offW2 : x->offb1);
+  long hi = x->offW1 + K * H;
+  if (x->offb1 + H > hi) hi = x->offb1 + H;
+  if (x->offW2 + H * C > hi) hi = x->offW2 + H * C;
+  if (x->offb2 + C > hi) hi = x->offb2 + C;
+  long bounds[DTF_XGMI_MAX_RANKS + 1];
+  int nb = 0;
+  for (int r = 1; r < x->world; ++r) {
+    const long st = a.start[r];
+    if (st > lo && st < hi && (nb == 0 || bounds[nb - 1] != st)) bounds[nb++] = st;
   }
-  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true, &sv);
+  for (int i = 0; i + 1 < nb; ++i)
+    if (bounds[i + 1] - bounds[i] < 32 * H + 16) return DTF_ERR_UNSUPPORTED;
+  return DTF_OK;
+}
+
+extern "C" int dtf_mlp_step_async(const DtfMlpDesc* d, int batch_index, int parity, const DtfXgDesc* x, void* stream) {
+  if (!d || !x) return DTF_ERR_NULL;
+  if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
+  if (!d->gW1 || !d->gb1 || !d->gW2 || !d->gb2) return DTF_ERR_NULL;     // valid (unused) gradient locations
+  XgParams a;
+  ShardView sv;
+  // x->compact == 1 means: no pull in front of this step -- the forward reads the variables from the shards.
+  const bool from_shards = x->compact == 1;
+  const int rc = shard_tables(d, x, a, sv, from_shards);
+  if (rc != DTF_OK) return rc;
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, 1.0f, (hipStream_t)stream, &a, true,
+                           from_shards ? &sv : nullptr);
+}
+
+// Gradient step of a worker whose variables live in parameter-server shards it has mapped: the forward reads W1 / b1 /
+// W2 / b2 from the shards (no pull launch in front), the backward writes grad_scale * gradient to d->gW1 .. gb2 as
+// dtf_mlp_step_grad does.  x: the shard table as for dtf_mlp_step_async (state, step_index and compact are not used).
+extern "C" int dtf_mlp_step_grad_shards(const DtfMlpDesc* d, int batch_index, int parity, float grad_scale,
+                                        const DtfXgDesc* x, void* stream) {
+  if (!d || !x) return DTF_ERR_NULL;
+  if (!dtf_step2_supported(d->batch, d->in_dim, d->hidden, d->classes)) return DTF_ERR_UNSUPPORTED;
+  if (!d->gW1 || !d->gb1 || !d->gW2 || !d->gb2) return DTF_ERR_NULL;
+  XgParams a;
+  ShardView sv;
+  const int rc = shard_tables(d, x, a, sv, true);
+  if (rc != DTF_OK) return rc;
+  return launch_step2_impl(d, batch_index, parity, DTF_HEAD_GRAD, grad_scale, (hipStream_t)stream, nullptr, false, &sv);
 }
 
 int dtf_launch_step2(const DtfMlpDesc* d, long batch_index, int parity, int mode, float grad_scale,

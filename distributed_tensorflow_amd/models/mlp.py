@@ -315,16 +315,21 @@ class MLPEngine:
         self._slot_descs[slot] = (base, d)
         return d
 
-    def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0, slot: Optional[int] = None):
+    def step_grad(self, batch_index: Optional[int] = None, scale: float = 1.0, slot: Optional[int] = None,
+                  shards: Optional["hb.DtfXgDesc"] = None):
         """Gradients of mini-batch ``batch_index`` into the gradient tensors (or into gradient slot ``slot``,
-        see :meth:`bind_grad_slots`); no update."""
+        see :meth:`bind_grad_slots`); no update.  ``shards`` (GPU): the forward reads the variables from these
+        mapped parameter-server shards instead of the engine's own copy -- no pull in front of the step."""
         self._carry_pos = None
         if self.g is None and slot is None:
             raise RuntimeError("engine was built without gradient tensors")
         bi = self._bi(batch_index)
         if self.on_gpu:
             d = self._descriptor() if slot is None else self._slot_descriptor(slot)
-            hb.mlp_step_grad(d, bi, self.parity, scale)
+            if shards is not None:
+                hb.mlp_step_grad_shards(d, bi, self.parity, scale, shards)
+            else:
+                hb.mlp_step_grad(d, bi, self.parity, scale)
             self.parity ^= 1
         elif slot is None:
             self._cpu_step(bi, False, scale)

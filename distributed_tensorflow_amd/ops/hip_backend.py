@@ -132,6 +132,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.dtf_mlp_step_xg.restype = C.c_int
     lib.dtf_mlp_step_async.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, C.POINTER(DtfXgDesc), vp]
     lib.dtf_mlp_step_async.restype = C.c_int
+    lib.dtf_mlp_step_grad_shards.argtypes = [C.POINTER(DtfMlpDesc), i32, i32, f32, C.POINTER(DtfXgDesc), vp]
+    lib.dtf_mlp_step_grad_shards.restype = C.c_int
     lib.dtf_enable_peer_access.argtypes = [i32, i32]
     lib.dtf_enable_peer_access.restype = C.c_int
     lib.dtf_xgmi_pull.argtypes = [vp, i32, i64, vp, vp]
@@ -692,6 +694,12 @@ def mlp_step_async(desc: DtfMlpDesc, batch_index: int, parity: int, xg: DtfXgDes
     """Forward + a backward that pushes ``shard -= lr * g`` element-wise into the shards described by ``xg``."""
     _check(require().dtf_mlp_step_async(C.byref(desc), int(batch_index), int(parity), C.byref(xg), _stream()),
            "dtf_mlp_step_async")
+
+
+def mlp_step_grad_shards(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float, shards: DtfXgDesc):
+    """Gradient step whose forward reads the variables from mapped parameter-server shards (no pull in front)."""
+    _check(require().dtf_mlp_step_grad_shards(C.byref(desc), int(batch_index), int(parity), float(grad_scale),
+                                              C.byref(shards), _stream()), "dtf_mlp_step_grad_shards")
 
 
 def mlp_step_xg(desc: DtfMlpDesc, batch_index: int, parity: int, grad_scale: float, xg: DtfXgDesc):

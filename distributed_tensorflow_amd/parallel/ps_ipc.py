@@ -318,7 +318,10 @@ class IpcVariableStore:
 
     def step_counter_view(self) -> torch.Tensor:
         """The live ``global_step`` element in its owner's shard (one float of mapped device memory)."""
-        return self._params(self._gs_shard)[self._gs_off:self._gs_off + 1]
+        view = getattr(self, "_gs_view", None)
+        if view is None:
+            view = self._gs_view = self._params(self._gs_shard)[self._gs_off:self._gs_off + 1]
+        return view
 
     def push_descriptor(self, offsets: dict, bump_step: bool = True, read_shards: bool = False) -> "hb.DtfXgDesc":
         """Arguments of ``hb.mlp_step_async`` for these shards: the backward launch itself applies ``-lr * g`` of

@@ -363,7 +363,7 @@ class Session:
             feed[k] = v
         cache: Dict[G.Tensor, Any] = {}
         needs_vars = any(self._reads_variables(f) for f in flist if isinstance(f, G.Tensor))
-        shard_step = self._fused_async_call(flist, feed) if (needs_vars and self.store.is_remote) else None
+        shard_step = self._shard_served_call(flist, feed) if (needs_vars and self.store.is_remote) else None
         if needs_vars and self.store.is_remote and shard_step is None:
             self._pull()
         # train ops first: they define the forward pass the other fetches see.  Variables fetched
@@ -380,13 +380,16 @@ class Session:
                         if self._gs_mirror is None:
                             self._gs_mirror = int(round(float(self._var_view(f).item())))
                         cache[f] = torch.tensor(float(self._gs_mirror))         # host value, pre-update
-                    elif shard_step is not None and f is gs_var:
+                    elif shard_step == "pushed" and f is gs_var:
                         # a call served by the fused asynchronous step has no pull in front, and the step itself hands
                         # back the counter as it was before its push (the reference's fetch next to the train op reads
                         # it unordered, tfdist_between.py:94,102): _run_train puts it into the cache
                         pass
                     else:
-                        view = self._var_view(f)
+                        # (a synchronous step that reads the variables from the shards has no pull in front either:
+                        # the counter is read where it lives)
+                        view = self.store.step_counter_view() if (shard_step == "deposit" and f is gs_var) \
+                            else self._var_view(f)
                         if self._host_words is not None and view.numel() == 1 and not pending_used:
                             with torch.cuda.device(self.device):
                                 self._host_words[2:3].copy_(view.reshape(1), non_blocking=True)
@@ -698,10 +701,12 @@ class Session:
         eng._async_desc = desc
         return desc
 
-    def _fused_async_call(self, flist, feed):
-        """For a ``sess.run`` of ONE asynchronous train op of the fused model on mapped shards whose other fetches are
-        served by the step itself (cost, accuracy, summaries of them) or are its step counter: the counter's element in
-        its owner's shard -- such a call needs no pull (True).  None: pull as usual."""
+    def _shard_served_call(self, flist, feed):
+        """For a ``sess.run`` of ONE train op of the fused model on mapped shards whose other fetches are served by the
+        step itself (cost, accuracy, summaries of them) or are its step counter: how the step works on the shards, so
+        that the call needs no pull -- "pushed" (asynchronous: forward from the shards, backward that pushes) or
+        "deposit" (synchronous replicas: forward from the shards, gradient into the worker's mailbox).  None: pull as
+        usual."""
         trains = [f for f in flist if _is(f, "train")]
         if len(trains) != 1 or not hasattr(self.store, "push_descriptor"):
             return None
@@ -720,15 +725,39 @@ class Session:
             elif not self._served_by_step(f, m, plan):
                 return None
         opt = train_op.attrs["optimizer"]
-        if isinstance(opt, SyncReplicasOptimizer) or opt.use_locking:
-            return None
         if not self._local_step_ready:           # (the shards are allocated and mapped before the first view of them)
             self.store.sync_local_step()
             self._local_step_ready = True
         eng = self._engine_for(m, int(feed[m["x"]].shape[0]))
-        if self._async_descriptor(train_op, eng, m) is None:
+        if isinstance(opt, SyncReplicasOptimizer):
+            if self._mailbox_gradients(eng, m) and self._sync_shards(eng, m) is not None:
+                return "deposit"
             return None
-        return True
+        if opt.use_locking or self._async_descriptor(train_op, eng, m) is None:
+            return None
+        return "pushed"
+
+    def _sync_shards(self, eng: MLPEngine, m):
+        """Shard table for the gradient step of a synchronous replica whose forward reads the variables from the mapped
+        shards (``MLPEngine.step_grad(shards=...)``), or None.  Decided once per engine."""
+        desc = getattr(eng, "_sync_shards_desc", False)
+        if desc is not False:
+            return desc
+        desc = None
+        if (self.device.type == "cuda" and hasattr(self.store, "push_descriptor")
+                and os.environ.get("DTF_SYNC_FOLD_PULL", "1") != "0"):
+            from .ops import hip_backend as hb
+
+            offs = {r: self.layout.var_range[m[r].op_name][0] for r in ("W1", "b1", "W2", "b2")}
+            try:
+                desc = self.store.push_descriptor(offs, bump_step=False, read_shards=True)
+                # loads the kernels and checks the shard table (zero times the gradient, into the session's own slab)
+                eng.step_grad(0, 0.0, shards=desc)
+                eng.reset_step_workspace(0)
+            except (ValueError, RuntimeError, hb.HipKernelError):
+                desc = None
+        eng._sync_shards_desc = desc
+        return desc
 
     def _served_by_step(self, f, m, plan, _depth: int = 0) -> bool:
         """True when ``f`` is computed from the fused step's own results (its loss, its batch accuracy, summaries of
@@ -762,7 +791,7 @@ class Session:
                     applied = True
                 elif sync and self._mailbox_gradients(eng, m):
                     # the backward kernel writes this step's gradient straight into the worker's mailbox row
-                    eng.step_grad(0, 1.0, slot=self.store.next_mailbox_slot())
+                    eng.step_grad(0, 1.0, slot=self.store.next_mailbox_slot(), shards=self._sync_shards(eng, m))
                     applied = "deposited"
                 elif not sync and self._async_descriptor(train_op, eng, m) is not None:
                     # asynchronous worker on mapped shards: the forward reads the variables from the shards, the
