@@ -265,3 +265,58 @@ def test_the_single_process_all_reduce_binding_of_the_host_loop_towers_reaches_r
     nccl.all_reduce([g])
     torch.cuda.synchronize()
     assert torch.equal(g.cpu(), torch.arange(1000, dtype=torch.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_gradient_step_that_reads_the_variables_from_shards_equals_the_plain_one(n_shards):
+    """``MLPEngine.step_grad(shards=...)`` (a synchronous per-batch worker on mapped parameter-server shards: no pull in
+    front of the step): with shards that hold the same values as the engine's own copy -- one shard, or whole variables
+    dealt over two buffers as ``replica_device_setter`` deals them (tfdist_between.py:37-47) -- the gradients and the
+    step's statistics are those of the plain gradient step and of the fp32 oracle within rounding (the engine's own copy of
+    the variables holds NaNs here: it is not read)."""
+    import torch
+
+    from distributed_tensorflow_amd.models.mlp import MLPEngine
+    from distributed_tensorflow_amd.ops import hip_backend as hb
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.variables import ShardLayout, assign_shards, mlp_var_specs
+
+    dev = torch.device("cuda", 0)
+    specs = mlp_var_specs()
+    assign_shards(specs, n_shards)
+    layout = ShardLayout(specs, n_shards, mode="by_variable")
+    slab = layout.new_slab(dev)
+    layout.initialize(slab, 5)
+    grads = [layout.new_slab(dev), layout.new_slab(dev)]
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(200, 784, generator=gen).to(dev)
+    y = torch.eye(10)[torch.randint(0, 10, (200,), generator=gen)].to(dev)
+    names = {"W1": "weights/Variable", "b1": "biases/Variable", "W2": "weights/Variable_1", "b2": "biases/Variable_1"}
+    # the "parameter-server shards": buffers of their own with the shards' ranges of the slab
+    shards = [slab[a:b].clone() for a, b in (layout.shard_range[k] for k in range(n_shards))]
+    d = hb.DtfXgDesc()
+    for k in range(n_shards):
+        d.shard_start[k] = layout.shard_range[k][0]
+        d.inbox[k] = shards[k].data_ptr()
+    d.shard_start[n_shards] = layout.shard_range[n_shards - 1][1]
+    d.state, d.n, d.rank, d.world, d.timeout_ms, d.step_index, d.compact = None, 0, 0, n_shards, 0, -1, 1
+    d.offW1, d.offb1, d.offW2, d.offb2 = (layout.var_range[names[r]][0] for r in ("W1", "b1", "W2", "b2"))
+    out = []
+    for use_shards in (False, True):
+        own = slab.clone() if not use_shards else torch.full_like(slab, float("nan"))   # (the own copy is not read)
+        eng = MLPEngine({r: layout.view(own, n) for r, n in names.items()},
+                        {r: layout.view(grads[use_shards], n) for r, n in names.items()}, batch=100, lr=0.1, act="sigmoid")
+        eng.bind_data(x, y)
+        eng.step_grad(1, 0.5, shards=d if use_shards else None)
+        torch.cuda.synchronize()
+        out.append((grads[use_shards].clone(), eng.last_loss()))
+    # (the logits are summed with float atomics: two runs of one kernel agree within rounding, not bit for bit)
+    assert bool(torch.isfinite(out[1][0]).all()) and abs(out[0][1] - out[1][1]) <= 1e-5 * max(1.0, abs(out[0][1]))
+    p = layout.mlp_views(slab)
+    want = ref.mlp_grads(x[100:200], y[100:200], p["W1"], p["b1"], p["W2"], p["b2"])
+    for which in (0, 1):
+        got = layout.mlp_views(out[which][0])
+        for k in ("W1", "b1", "W2", "b2"):
+            err = float((got[k] - 0.5 * want["d" + k]).abs().max())
+            assert err <= 2e-5 * max(1.0, float(want["d" + k].abs().max())), (which, k, err)
