@@ -30,7 +30,9 @@ With one GPU the line also carries the reference's scripts in their literal form
 headline: ``sec_per_epoch_per_batch_tier`` (``tfsingle.py``: one ``sess.run`` with feed and four fetches and one event
 record per batch; DTF_BENCH_PER_BATCH=0 skips it) and ``per_batch_clusters`` (``tfdist_between.py`` /
 ``tfdist_between_sync.py`` as separate ps and worker tasks sharing the GPU: asynchronous 1 ps + 1 worker,
-1 ps + 2 workers and 2 ps + 2 workers, synchronous 1 ps + 2 workers; DTF_BENCH_CLUSTERS=0 skips it, on the CPU it runs only with =1).
+1 ps + 2 workers and 2 ps + 2 workers, synchronous 1 ps + 2 workers; recipes with several workers twice, the faster run
+reported: client processes that time-share ONE GPU take turns when their hardware queues land on one of its pipes;
+DTF_BENCH_CLUSTERS=0 skips it, on the CPU it runs only with =1).
 """
 from __future__ import annotations
 

