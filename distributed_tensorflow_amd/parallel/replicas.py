@@ -858,6 +858,58 @@ class XgmiAsyncTrainer(_BaseTrainer):
             torch.cuda.synchronize(self.device)
             self.engine.reset_step_workspace(0)
             self._push_desc = self.shards.step_descriptor(offs, self.step_index, read_shards=self.fold_pull)
+            self.form_probe_us = None
+            if (self.world > 1 and self.use_graph and os.environ.get("DTF_ASYNC_CALIBRATE", "1") != "0"):
+                self._choose_form(offs)
+
+    def _choose_form(self, offs):
+        """Which form of the step is fastest HERE is measured, not assumed: with the shards behind xGMI links a forward
+        that reads the variables from them issues many small remote reads where a pull moves each shard once in bulk,
+        and the atomics of the pushing backward contend differently from a push kernel's whole vectors.  The forms --
+        forward from the shards + pushing backward (2 launches), pull + pushing backward (3), pull + gradient launches +
+        push kernel (4) -- are each captured as a chunk with a learning rate of zero and no step count (the shards receive
+        ``+ 0`` while the other workers go on), replayed and timed with device events; every worker decides for itself."""
+        want = (self.fold_pull, self.fused_push)
+        n = min(self.chunk, self.engine.batches_per_epoch, 20)
+        times = {}
+        keep_lr = self.engine.lr.clone()
+        self.engine.lr.zero_()
+        self._dry = True
+        try:
+            for name, fold, fused in (("forward from the shards", True, True), ("pull, pushing backward", False, True),
+                                      ("pull, push kernel", False, False)):
+                if fold and not self.fold_pull:
+                    continue
+                self.fold_pull, self.fused_push = fold, fused
+                self._push_desc = self.shards.step_descriptor(offs, -1, read_shards=fold) if fused else None
+                g = self._capture(0, n, 0)
+                start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(2):
+                    g.replay()
+                start.record()
+                for _ in range(6):
+                    g.replay()
+                stop.record()
+                stop.synchronize()
+                times[name] = (1000.0 * start.elapsed_time(stop) / (6 * n), fold, fused)
+                del g
+        except Exception:  # noqa: BLE001 -- a runtime that cannot capture these steps: keep the default form
+            times = {}
+        finally:
+            self._dry = False
+            self.engine.lr.copy_(keep_lr)
+            torch.cuda.synchronize(self.device)
+            self.engine.reset_step_workspace(0)
+        if times:
+            best = min(times.values(), key=lambda v: v[0])
+            self.fold_pull, self.fused_push = best[1], best[2]
+            self.form_probe_us = {k: round(v[0], 2) for k, v in times.items()}
+        else:
+            self.fold_pull, self.fused_push = want
+        self._push_desc = (self.shards.step_descriptor(offs, self.step_index, read_shards=self.fold_pull)
+                           if self.fused_push else None)
+
+    _dry = False
 
     def _one_step(self, batch_index: int):
         if self.fold_pull:
@@ -873,7 +925,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
         with span("step"):
             self.engine.step_grad(batch_index, 1.0)
         with span("push_apply"):
-            self.shards.push_sgd(self.grads, self.lr, self.step_index)
+            self.shards.push_sgd(self.grads, self.lr, -1 if self._dry else self.step_index)
 
     def _capture(self, pos: int, n: int, parity: int):
         # No warm-up replay: a step writes the shared shards, which cannot be rolled back.
@@ -903,16 +955,18 @@ class XgmiAsyncTrainer(_BaseTrainer):
         self.shards.close()
 
     def describe(self):
+        probe = getattr(self, "form_probe_us", None)
+        probed = (" [measured us/step: " + ", ".join(f"{k} {v}" for k, v in probe.items()) + "]") if probe else ""
         if self.fold_pull:
             return (f"async PS dp{self.world}: shard per GPU in HBM, forward that reads the variables from the shards -> "
                     f"backward that pushes -lr*g per element into the owning shard with float atomics (2 launches/step) "
-                    f"through peer mappings, no barrier"
+                    f"through peer mappings, no barrier" + probed
                     + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
         push = ("forward -> backward that pushes -lr*g per element into the owning shard with float atomics "
                 "(3 launches/step)" if self.fused_push else
                 "2 launches -> one-sided lock-free SGD push (1 launch)")
         return (f"async PS dp{self.world}: shard per GPU in HBM, one-sided pull (1 launch) -> {push} "
-                f"through peer mappings, no barrier"
+                f"through peer mappings, no barrier" + probed
                 + (", hipGraph chunks of %d" % self.chunk if self.use_graph else ", eager"))
 
 
