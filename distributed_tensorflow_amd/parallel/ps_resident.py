@@ -110,23 +110,29 @@ class PsResidentTrainer(_BaseTrainer):
                 torch.cuda.synchronize(self.device)
                 self.engine.reset_step_workspace(0)
             if self._push_desc is not None and fused_push == "auto" and self.use_graph:
-                self._choose_push(self.store.push_descriptor(offs, bump_step=False, read_shards=self.fold_pull))
+                self._choose_push(offs)
 
-    def _choose_push(self, dry_desc):
-        """Time both forms of the push against the live shards and keep the faster one.
+    def _choose_push(self, offs):
+        """Time the forms of the step against the live shards and keep the fastest one.
 
         The atomics of the pushing backward travel as 64-byte requests (the 16 lanes of a tile row) and contend
         when several workers hit one shard; a push kernel per shard moves whole vectors but costs a launch per shard.  Which wins depends on how many shards there are, whether they sit
         on this GPU or behind xGMI, and who else is pushing, so it is measured: a chunk of steps of each form is
-        captured with a learning rate of zero and no step count (the shards receive ``+ 0``), replayed, timed."""
-        real = self._push_desc
+        captured with a learning rate of zero and no step count (the shards receive ``+ 0``), replayed, timed.
+        The same goes for the pull: a forward that reads the variables from the shards saves a launch, but with the
+        shards behind xGMI links it issues many small remote reads where a pull moves each shard once in bulk."""
+        real_fold = self.fold_pull
         n = min(self.chunk, self.engine.batches_per_epoch)
         times = {}
         self._dry = True
         self.engine.lr.zero_()
+        forms = [("fused", False, self.store.push_descriptor(offs, bump_step=False)), ("kernel", False, None)]
+        if real_fold:
+            forms.insert(0, ("fused, forward from the shards", True,
+                             self.store.push_descriptor(offs, bump_step=False, read_shards=True)))
         try:
-            for form, desc in (("fused", dry_desc), ("kernel", None)):
-                self._push_desc = desc
+            for form, fold, desc in forms:
+                self._push_desc, self.fold_pull = desc, fold
                 g = self._capture(0, n, 0)
                 start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for _ in range(3):
@@ -147,9 +153,10 @@ class PsResidentTrainer(_BaseTrainer):
             torch.cuda.synchronize(self.device)
             self.engine.reset_step_workspace(0)
         self.push_probe_us = {k: round(v, 2) for k, v in times.items()} or None
-        self._push_desc = real if (not times or times["fused"] <= times["kernel"]) else None
-        if self._push_desc is None:
-            self.fold_pull = False
+        best = min(times, key=times.get) if times else ("fused, forward from the shards" if real_fold else "fused")
+        self.fold_pull = best == "fused, forward from the shards"
+        self._push_desc = None if best == "kernel" else self.store.push_descriptor(
+            offs, bump_step=self.bump_step, read_shards=self.fold_pull)
 
     def _one_step(self, batch_index: int):
         if self._push_desc is not None and self.fold_pull:
