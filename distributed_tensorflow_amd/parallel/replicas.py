@@ -817,13 +817,17 @@ class XgmiAsyncTrainer(_BaseTrainer):
 
     name = "xgmi_async"
 
-    def __init__(self, *a, group=None, fused_push: bool = True, fold_pull: bool = True, **kw):
+    def __init__(self, *a, group=None, fused_push="auto", fold_pull="auto", **kw):
         super().__init__(*a, **kw)
         if self.device.type != "cuda":
             raise RuntimeError("the peer-mapped shards are a GPU path")
         from .xgmi import PeerShards
 
         self.group = group
+        # "auto" (both): start from the two-launch form and, with peers, let _choose_form measure; a bool forces a form
+        calibrate = fused_push == "auto" and fold_pull == "auto"
+        fused_push = True if fused_push == "auto" else fused_push
+        fold_pull = True if fold_pull == "auto" else fold_pull
         self.fused_push = bool(fused_push)
         # fold_pull: no pull launch either -- the forward reads W1 / b1 / W2 / b2 from the shards through the
         # mappings and snapshots W2 / b2 for the backward (2 launches per step; needs the fused push)
@@ -859,7 +863,7 @@ class XgmiAsyncTrainer(_BaseTrainer):
             self.engine.reset_step_workspace(0)
             self._push_desc = self.shards.step_descriptor(offs, self.step_index, read_shards=self.fold_pull)
             self.form_probe_us = None
-            if (self.world > 1 and self.use_graph and os.environ.get("DTF_ASYNC_CALIBRATE", "1") != "0"):
+            if (calibrate and self.world > 1 and self.use_graph and os.environ.get("DTF_ASYNC_CALIBRATE", "1") != "0"):
                 self._choose_form(offs)
 
     def _choose_form(self, offs):

@@ -1,6 +1,6 @@
 """One replica of the peer-mapped exchange test (several of these share the GPU).
 
-usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|sync2c|sync2p|sync_backup|async|async_sep]
+usage: _xgmi_worker.py RANK WORLD PORT STEPS USE_GRAPH UNCACHED [sync|sync2|sync2c|sync2p|sync_backup|async|async_sep|async_auto]
 Prints one JSON line: health, bitwise agreement of the replicas, distance to a CPU fp32 reference
 (sync), or the state of the shared shards after every worker finished (async).
 """
@@ -19,6 +19,7 @@ from distributed_tensorflow_amd.parallel.replicas import build_replica_trainer  
 
 
 def run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=True):
+    # fused_push="auto": the worker measures the forms of its step against the live shards and keeps the fastest
     t = build_replica_trainer("xgmi_async", device=dev, dataset=ds, batch=B, lr=lr, seed=1, rank=rank, world=world,
                               chunk=3, use_graph=bool(use_graph), fused_push=fused_push)
     p0 = t.params.clone()
@@ -54,8 +55,9 @@ def main():
     x = torch.rand(rows, 784, generator=g)
     y = torch.eye(10)[torch.randint(0, 10, (rows,), generator=g)]
     ds = DeviceDataset(x, y, dev, B, seed=1000 + rank)
-    if mode in ("async", "async_sep"):
-        return run_async(rank, world, steps, use_graph, dev, ds, B, lr, fused_push=mode == "async")
+    if mode in ("async", "async_sep", "async_auto"):
+        return run_async(rank, world, steps, use_graph, dev, ds, B, lr,
+                         fused_push="auto" if mode == "async_auto" else mode == "async")
     backup = mode == "sync_backup"          # the first world - 1 gradients of a step count (backup replicas)
     extra = {} if mode in ("sync2", "sync2c", "sync2p") else {"uncached_grads": bool(uncached)}
     if backup:

@@ -82,17 +82,21 @@ def test_backup_replicas_the_first_gradients_to_arrive_count_and_every_replica_a
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world,use_graph,mode", [(2, False, "async"), (3, True, "async"), (4, True, "async"),
-                                                  (2, True, "async_sep")])
+                                                  (2, True, "async_sep"), (3, True, "async_auto")])
 def test_async_workers_update_shared_shards_one_sidedly(world, use_graph, mode):
     """``async``: the push is part of the backward launch (float atomics per element); ``async_sep``: a launch of
-    its own."""
+    its own; ``async_auto``: every worker measures the forms of its step against the live shards (with a learning rate
+    of zero and no step count) and keeps the fastest -- which one that is does not change what is computed."""
     steps = 8
     res = _run_replicas(world, steps, use_graph, mode=mode)
     for r in res:
         assert r["finite"] and r["identical"], r              # after the last push everybody pulls the same shards
         assert r["global_step"] == world * steps, r           # every push counted, atomically
         assert r["moved"] > 1e-3 and r["loss_after"] < r["loss_before"], r
-        assert ("float atomics" if mode == "async" else "one-sided lock-free SGD push") in r["describe"]
+        if mode == "async_auto":
+            assert "measured us/step: forward from the shards" in r["describe"]
+        else:
+            assert ("float atomics" if mode == "async" else "one-sided lock-free SGD push") in r["describe"]
 
 
 @pytest.mark.gpu
