@@ -391,10 +391,12 @@ class Session:
                         view = self.store.step_counter_view() if (shard_step == "deposit" and f is gs_var) \
                             else self._var_view(f)
                         if self._host_words is not None and view.numel() == 1 and not pending_used:
-                            with torch.cuda.device(self.device):
+                            with self._on_device():
                                 self._host_words[2:3].copy_(view.reshape(1), non_blocking=True)
                                 pending = _PendingScalar(self._host_words, self._host_evt_var, 2)
-                                pending.event.record()
+                                # (with the device named: record() on its own asks torch.cuda.current_stream(), whose
+                                # device lookup is a driver call of 11 us)
+                                pending.event.record(torch.cuda.current_stream(self.device))
                             cache[f] = pending
                             pending_used = True
                         else:
@@ -888,9 +890,11 @@ class Session:
         if self._host_words is None or stats.device.type != "cuda":
             return stats.cpu()
         n = stats.numel()            # 2, or 3 with the step counter of a fused asynchronous step
-        with torch.cuda.device(self.device):
+        with self._on_device():
             self._host_words[0:n].copy_(stats, non_blocking=True)
-            self._host_evt.record()
+            # (with the device named: record() on its own asks torch.cuda.current_stream(), whose device lookup is a
+            # driver call of 11 us; _on_device() instead of a device guard per step for the same reason)
+            self._host_evt.record(torch.cuda.current_stream(self.device))
         self._host_evt.synchronize()
         return self._host_words[0:n].clone()
 
