@@ -196,9 +196,9 @@ class RemoteVariableStore:
         for k in range(self.n):
             a, b = self.layout.shard_range[k]
             if b > a:
-                self._c(k).buf_axpy(SHARD_BUF, -float(lr), self._ghost[a:b], locked=use_locking)
-        if bump_step:
-            self._c(self._gs_shard).buf_add_scalar(SHARD_BUF, self._gs_off_in_shard, 1.0)
+                # (the shard that holds global_step counts the update in the same request)
+                self._c(k).buf_axpy(SHARD_BUF, -float(lr), self._ghost[a:b], locked=use_locking,
+                                    bump=self._gs_off_in_shard if (bump_step and k == self._gs_shard) else None)
 
     # -- SyncReplicas protocol ---------------------------------------------------------------
     def push_accumulate(self, grads: torch.Tensor) -> bool:

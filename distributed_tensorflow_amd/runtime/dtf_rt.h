@@ -19,6 +19,7 @@ extern "C" {
 #define DTF_FLAG_RELEASE 4  /* ACC_TAKE_APPLY: also bump the step counter and deal the round's tokens */
 #define DTF_FLAG_THEN_POP 8 /* ACC_APPLY: key = accumulator \x01 queue; then block for an item of that queue */
 #define DTF_FLAG_FANOUT 2   /* QPUSH: key is a prefix, the payload goes to the queues key/0 .. key/(a1-1) */
+#define DTF_FLAG_BUMP 16    /* BUF_AXPY: then add 1 to element a1 of the buffer (the step counter); its value is returned */
 
 // operations
 #define DTF_OP_PING 0

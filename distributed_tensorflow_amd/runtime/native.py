@@ -24,6 +24,7 @@ FLAG_LOCK = 1
 FLAG_FANOUT = 2
 FLAG_RELEASE = 4
 FLAG_THEN_POP = 8
+FLAG_BUMP = 16
 (OP_PING, OP_SET, OP_GET, OP_ADD, OP_WAIT_GE, OP_QPUSH, OP_QPOP, OP_DEL, OP_SHUTDOWN, OP_QLEN,
  OP_BUF_CREATE, OP_BUF_WRITE, OP_BUF_READ, OP_BUF_AXPY, OP_ACC_APPLY, OP_ACC_TAKE_APPLY, OP_ACC_SET_STEP,
  OP_BUF_ADD_SCALAR, OP_ACC_INFO, OP_QPUSH_POP, OP_QPOP_N) = range(21)
@@ -271,11 +272,16 @@ class StoreClient:
         self._ok(st, f"buf_read {key}")
         return out
 
-    def buf_axpy(self, key: str, alpha: float, g: np.ndarray, offset: int = 0, locked: bool = False):
-        """buf[offset:offset+len(g)] += alpha * g, executed on the server."""
+    def buf_axpy(self, key: str, alpha: float, g: np.ndarray, offset: int = 0, locked: bool = False,
+                 bump: Optional[int] = None) -> int:
+        """buf[offset:offset+len(g)] += alpha * g, executed on the server.  ``bump``: element of the buffer that counts
+        the updates (global_step): one is added to it in the same request and its new value returned."""
         g = np.ascontiguousarray(g, dtype=np.float32)
-        st, _, _ = self._call(OP_BUF_AXPY, key, flags=FLAG_LOCK if locked else 0, a0=offset, f0=alpha, payload=g)
+        flags = (FLAG_LOCK if locked else 0) | (FLAG_BUMP if bump is not None else 0)
+        st, v, _ = self._call(OP_BUF_AXPY, key, flags=flags, a0=offset, a1=int(bump) if bump is not None else 0, f0=alpha,
+                              payload=g)
         self._ok(st, f"buf_axpy {key}")
+        return v
 
     def buf_add_scalar(self, key: str, offset: int, delta: float) -> int:
         st, v, _ = self._call(OP_BUF_ADD_SCALAR, key, a0=offset, f0=delta)

@@ -428,11 +428,20 @@ void serve_connection(Server* s, Server::Conn* self) {
         const float alpha = static_cast<float>(h.f0);
         const float* g = reinterpret_cast<const float*>(payload.data());
         float* p = e->buf.data() + h.a0;
+        if ((h.flags & DTF_FLAG_BUMP) && (h.a1 < 0 || static_cast<size_t>(h.a1) >= e->buf.size())) {
+          r.status = DTF_RT_BAD_REQUEST;
+          break;
+        }
         if (h.flags & DTF_FLAG_LOCK) {
           std::lock_guard<std::mutex> lk(e->mu);
           for (size_t i = 0; i < n; ++i) p[i] += alpha * g[i];
         } else {
           axpy_unlocked(p, g, alpha, n);
+        }
+        if (h.flags & DTF_FLAG_BUMP) {   // the step counter lives in this buffer: count the update in the same request
+          std::lock_guard<std::mutex> lk(e->mu);
+          e->buf[h.a1] += 1.0f;
+          r.value = static_cast<int64_t>(e->buf[h.a1]);
         }
         break;
       }

@@ -77,6 +77,14 @@ def test_buffers_and_server_side_sgd(server):
         c.buf_read("shard", 10, offset=995)
     with pytest.raises(RuntimeError):
         c.buf_axpy("missing", 1.0, g)
+    # an update that is counted in the same request: the buffer's step counter (element 999 here) goes up by one per
+    # call and its new value comes back (an asynchronous worker's push over tcp: one round trip, not two)
+    c.buf_write("shard", np.array([0, 1, 2, 3], dtype=np.float32), offset=996)
+    assert c.buf_axpy("shard", 2.0, np.ones(3, np.float32), offset=996, bump=999) == 4
+    assert c.buf_axpy("shard", 2.0, np.ones(3, np.float32), offset=996, locked=True, bump=999) == 5
+    assert list(c.buf_read("shard", 4, offset=996)) == [4, 5, 6, 5]
+    with pytest.raises(RuntimeError):
+        c.buf_axpy("shard", 1.0, g, bump=1000)                   # a counter outside the buffer
     c.close()
 
 
